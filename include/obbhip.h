@@ -1,0 +1,130 @@
+/*
+ * obbhip.h -- C-ABI of libobbhip.so: the MI355X (gfx950) drop-in for the Detect_OBB.py sliding-window
+ * oriented-box inference path of Abolfazlmsl/Oriented-Object-Detection.
+ *
+ * The reference has no FFI: its seams are plain Python callables.  Each entry point below
+ * names the reference interface it replaces (file:line in /root/reference).  Rules of the boundary:
+ *   - plain pointers and sizes only; every DATA pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller allocates every buffer; the library owns only the context (weights, workspaces, hipGraphs);
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*); no hidden synchronisation except
+ *     where a function is documented "(synchronises)";
+ *   - int status return (0 = ok, <0 = error) + obb_last_error(); nothing throws across the boundary;
+ *   - invalid / degenerate polygons yield IoU 0.0, not an error (Detect_OBB.py:150-151).
+ *
+ * Record layout shared by the detection-level calls ("det arrays"), all SoA:
+ *   boxes  double[n*8]   x1,y1,...,x4,y4  global pixel coordinates   (Detect_OBB.py:256-260)
+ *   cls    int32[n]                                                   (Detect_OBB.py:261)
+ *   conf   double[n]     float32 confidences widened to double        (Detect_OBB.py:231)
+ */
+#ifndef OBBHIP_H
+#define OBBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBB_OK 0
+#define OBB_ERR_INVALID (-1) /* bad argument                          */
+#define OBB_ERR_HIP (-2)     /* a HIP runtime call failed             */
+#define OBB_ERR_STATE (-3)   /* e.g. forward before weights are loaded */
+#define OBB_ERR_FORMAT (-4)  /* malformed weight blob                 */
+
+typedef struct obb_ctx obb_ctx;
+typedef void *obb_stream_t; /* hipStream_t */
+
+int obb_version(void);
+/* One context per device / rank.  (synchronises) */
+int obb_ctx_create(int device, obb_ctx **out);
+int obb_ctx_destroy(obb_ctx *ctx);
+/* Last error text of this context (or of the calling thread when ctx == NULL). */
+const char *obb_last_error(const obb_ctx *ctx);
+
+/* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */
+/* out[i] = IoU(a[i], b[i]); a, b: double[m*8].  Replaces Shapely Polygon/is_valid/intersection/area per pair. */
+int obb_poly_iou_pairs(obb_ctx *ctx, const double *a, const double *b, int64_t m, double *out, obb_stream_t s);
+/* out[i*nb+j] = IoU(a[i], b[j]) if cls_a[i]==cls_b[j] (or either cls pointer is NULL), else 0.
+ * The O(N1*N2) loops of Detect_OBB.py:387-403 and :541-547. */
+int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int64_t na, const double *b,
+                        const int32_t *cls_b, int64_t nb, double *out, obb_stream_t s);
+
+/* ------------------------------------------------------------------ S3: merge_detections  (Detect_OBB.py:176-200) */
+/* order[n] = stable descending argsort of key (Python list.sort(key=conf, reverse=True), Detect_OBB.py:183). */
+int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *order, obb_stream_t s);
+/* Pair-suppression bit matrix over boxes already in sorted order: bit j of mask[i*W + j/64] (W = ceil(n/64)) is set
+ * iff j > i, cls equal and IoU(i,j) >= thr  (Detect_OBB.py:193). */
+int obb_nms_mask(obb_ctx *ctx, const double *boxes_sorted, const int32_t *cls_sorted, int64_t n, double thr,
+                 uint64_t *mask, obb_stream_t s);
+/* Greedy scan of that matrix (Detect_OBB.py:186-198): keep[i] in sorted order, *n_keep = number kept. */
+int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
+/* The whole function: sort + mask + scan.  order[n] (sorted position -> input index), keep[n] (sorted order). */
+int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n,
+                         double thr, int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
+/* Batched form for the per-tile call at Detect_OBB.py:264: nseg independent segments, segment k owning rows
+ * [seg_off[k], seg_off[k+1]) (device int32[nseg+1]); order holds GLOBAL row indices per sorted position. */
+int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf,
+                       const int32_t *seg_off, int32_t nseg, int64_t n, double thr, int32_t *order, uint8_t *keep,
+                       obb_stream_t s);
+
+/* ------------------------------------------------------------------ S4: cross_scale_consensus_filter  (Detect_OBB.py:347-423) */
+/* Rows of all scales concatenated in ascending-scale order; scale k owns [off_host[k], off_host[k+1]).
+ * out_idx[<= n] receives kept row indices in the reference's output order, *n_out their count.
+ * Constants: CONS_IOU_PARTNER / CONS_LOW / CONS_HIGH (Detect_OBB.py:349-351). */
+int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int64_t *off_host,
+                  int32_t nscales, double iou_partner, double cons_low, double cons_high, int32_t *out_idx,
+                  int32_t *n_out, obb_stream_t s);
+
+/* ------------------------------------------------------------------ S5: detect_symbols  (Detect_OBB.py:202-266) */
+/* Tile rectangles (x, y, x2, y2) in the reference's visiting order (Detect_OBB.py:211-223).  Host-only helper:
+ * rects_host int32[max_tiles*4]; *n_tiles receives the full count even when it exceeds max_tiles. */
+int obb_tile_grid(int32_t H, int32_t W, int32_t tile, int32_t overlap, int32_t *rects_host, int64_t max_tiles,
+                  int64_t *n_tiles);
+/* Per-detection work of the tile loop (Detect_OBB.py:229-262): local float32 corners + integer tile offset in
+ * float64 (exact), inclusive border filter with `margin`, strike angle for class `strike_cls` (else 0.0).
+ * local_pts float[n*8], det_tile int32[n] (index into rects), rects int32[ntiles*4] (device). */
+int obb_tile_postprocess(obb_ctx *ctx, const float *local_pts, const int32_t *cls, const int32_t *det_tile, int64_t n,
+                         const int32_t *rects, int32_t ntiles, int32_t margin, int32_t strike_cls, double *gboxes,
+                         double *angle, uint8_t *inside, obb_stream_t s);
+/* Gather all full-size tiles of one image into an NHWC uint8 batch (Detect_OBB.py:218-220 crop, vectorised).
+ * image uint8[H*W*C]; rects device int32[ntiles*4] must all be tile x tile. */
+int obb_gather_tiles(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, const int32_t *rects,
+                     int32_t ntiles, int32_t tile, uint8_t *tiles_out, obb_stream_t s);
+/* Letterbox one partial crop to (out_h, out_w) the way the Ultralytics predictor does for a single image
+ * (LetterBox auto=True stride 32, pad value 114, bilinear resize only when the gain != 1; SURVEY.md Appendix A2;
+ * call site Detect_OBB.py:81-83).  Returns gain and left/top pad through *_host pointers. */
+int obb_letterbox(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, int32_t x, int32_t y, int32_t x2,
+                  int32_t y2, int32_t imgsz, uint8_t *out, int32_t out_h, int32_t out_w, obb_stream_t s);
+
+/* ------------------------------------------------------------------ S1: model(...) -> results[0].obb  (Detect_OBB.py:26,81-83,228-231) */
+/* Weight blob ("OBBW" format, produced by the Python side from BN-folded conv weights) for a
+ * YOLO11-OBB graph (ultralytics==8.3.196 yolo11-obb.yaml).  Host pointer.  (synchronises) */
+int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes);
+/* nc, input channels, number of anchors A for an (h, w) input, number of weight records. */
+int obb_model_info(const obb_ctx *ctx, int32_t h, int32_t w, int32_t *nc, int32_t *ch, int32_t *anchors, int32_t *nconv);
+/* OBBModel forward on B letterboxed inputs: tiles uint8[B*h*w*ch] (NHWC; BGR for ch==3 exactly as the reference
+ * passes crops, Detect_OBB.py:93) -> raw head float[B*A*(64+nc+1)] (per anchor: 4x16 DFL logits, nc class logits,
+ * 1 angle logit).  Preprocess (BGR->RGB, /255; Appendix A2) is fused into the first convolution. */
+int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s);
+/* Debug/parity tap: copy activation buffer `buf_id` of the last forward (bf16 NHWC widened to float) to out. */
+int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, int32_t buf_id, float *out, int64_t max_elems,
+                         int64_t *n_elems, int32_t *shape_hwc_host, obb_stream_t s);
+/* Decode (DFL, dist2rbox, angle, sigmoid; Appendix A4) + conf filter + class-offset ProbIoU Fast-NMS + max_det.
+ * out float[B*max_det*7] rows (x, y, w, h, conf, cls, theta) in score order; count int32[B]. */
+int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres,
+                   int32_t max_det, float *out, int32_t *count, obb_stream_t s);
+/* Pieces of the above for parity tests: decoded predictions float[B*A*(4+nc+1)] (x,y,w,h, cls scores, theta). */
+int obb_decode(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float *pred, obb_stream_t s);
+/* ProbIoU Fast-NMS on one candidate list: boxes float[n*5] (x,y,w,h,theta; class offset applied), scores float[n]. */
+int obb_probiou_nms(obb_ctx *ctx, const float *boxes, const float *scores, int64_t n, float iou_thres, int32_t *order,
+                    uint8_t *keep, obb_stream_t s);
+/* Result construction (regularize_rboxes, scale_boxes(xywh=True), xywhr2xyxyxyxy; Appendix A6; consumed at
+ * Detect_OBB.py:229-231).  det float[n*7] rows as written by obb_decode_nms; per-row letterbox params
+ * lb float[n*3] = (gain, pad_x, pad_y) or NULL for identity.  xywhr float[n*5], pts float[n*8]. */
+int obb_results(obb_ctx *ctx, const float *det, const float *lb, int64_t n, float *xywhr, float *pts, obb_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBBHIP_H */

@@ -150,6 +150,13 @@ double ora_poly_iou(const double *b1, const double *b2) {
     pt_t p[4], q[4], pc[4], qc[4];
     for (int i = 0; i < 4; ++i) { p[i].x = b1[2 * i]; p[i].y = b1[2 * i + 1]; q[i].x = b2[2 * i]; q[i].y = b2[2 * i + 1]; }
     if (!quad_valid(p) || !quad_valid(q)) return 0.0;
+    { /* GEOS short-circuits on strictly disjoint envelopes -> empty intersection, area exactly 0 */
+        double px0 = fmin(fmin(p[0].x, p[1].x), fmin(p[2].x, p[3].x)), px1 = fmax(fmax(p[0].x, p[1].x), fmax(p[2].x, p[3].x));
+        double py0 = fmin(fmin(p[0].y, p[1].y), fmin(p[2].y, p[3].y)), py1 = fmax(fmax(p[0].y, p[1].y), fmax(p[2].y, p[3].y));
+        double qx0 = fmin(fmin(q[0].x, q[1].x), fmin(q[2].x, q[3].x)), qx1 = fmax(fmax(q[0].x, q[1].x), fmax(q[2].x, q[3].x));
+        double qy0 = fmin(fmin(q[0].y, q[1].y), fmin(q[2].y, q[3].y)), qy1 = fmax(fmax(q[0].y, q[1].y), fmax(q[2].y, q[3].y));
+        if (px1 < qx0 || qx1 < px0 || py1 < qy0 || qy1 < py0) return 0.0;
+    }
     double a1 = fabs(shoelace2(p, 4)) * 0.5, a2 = fabs(shoelace2(q, 4)) * 0.5;
     make_ccw(p, 4, pc);
     make_ccw(q, 4, qc);

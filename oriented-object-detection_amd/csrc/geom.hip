@@ -1,0 +1,592 @@
+// Post-processing geometry kernels (fp64, wave64) + their C-ABI entry points.
+//
+//   obb_poly_iou_pairs / _matrix   <- compute_polygon_iou                 Detect_OBB.py:144-154
+//   obb_sort_desc_stable           <- detections.sort(key=conf, reverse)   Detect_OBB.py:183
+//   obb_nms_mask / obb_nms_reduce  <- merge_detections' greedy double loop Detect_OBB.py:186-198
+//   obb_merge_detections / _segments  (whole function; per-tile batched form for Detect_OBB.py:264)
+//   obb_consensus                  <- cross_scale_consensus_filter         Detect_OBB.py:347-423
+//   obb_tile_postprocess           <- per-detection body of detect_symbols Detect_OBB.py:229-262
+//
+// All of this is byte/compare work on KB..MB inputs: the kernels are HBM/latency bound, so the design rules are
+// coalesced SoA streams, LDS-resident segments, wave64 ballots/shuffles for the serial scans, and no GEMM shaping.
+#include "ctx.h"
+#include "geom_device.h"
+
+namespace obb {
+
+static constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------------ pair list / matrix
+
+__global__ __launch_bounds__(256) void k_iou_pairs(const double *__restrict__ a, const double *__restrict__ b, int64_t m,
+                                                  double *__restrict__ out) {
+    // stage 256 pairs x 2 x 64 B through LDS: global reads are contiguous 8 B/lane, LDS rows padded to 9 doubles so
+    // that the per-thread row reads (stride 72 B) are bank-conflict free
+    __shared__ double sa[256 * 9], sb[256 * 9];
+    int64_t base = (int64_t)blockIdx.x * 256;
+    int nloc = (int)((m - base) < 256 ? (m - base) : 256);
+    const double *ga = a + base * 8, *gb = b + base * 8;
+    for (int e = threadIdx.x; e < nloc * 8; e += 256) {
+        sa[(e >> 3) * 9 + (e & 7)] = ga[e];
+        sb[(e >> 3) * 9 + (e & 7)] = gb[e];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nloc) {
+        double pa[8], pb[8];
+        for (int k = 0; k < 8; ++k) { pa[k] = sa[threadIdx.x * 9 + k]; pb[k] = sb[threadIdx.x * 9 + k]; }
+        out[base + threadIdx.x] = poly_iou(pa, pb);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iou_matrix(const double *__restrict__ a, const int32_t *__restrict__ ca, int64_t na,
+                                                   const double *__restrict__ b, const int32_t *__restrict__ cb, int64_t nb,
+                                                   double *__restrict__ out) {
+    // block = 16 rows x 16.. cols tile: thread (ty, tx)
+    __shared__ double sa[16 * 8], sb[16 * 8];
+    __shared__ int32_t sca[16], scb[16];
+    int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
+    if (threadIdx.x < 128) {
+        int r = threadIdx.x >> 3, k = threadIdx.x & 7;
+        sa[threadIdx.x] = (i0 + r < na) ? a[(i0 + r) * 8 + k] : 0.0;
+    } else {
+        int t = threadIdx.x - 128;
+        int r = t >> 3, k = t & 7;
+        sb[t] = (j0 + r < nb) ? b[(j0 + r) * 8 + k] : 0.0;
+    }
+    if (threadIdx.x < 16) sca[threadIdx.x] = (ca && i0 + threadIdx.x < na) ? ca[i0 + threadIdx.x] : 0;
+    else if (threadIdx.x < 32) scb[threadIdx.x - 16] = (cb && j0 + threadIdx.x - 16 < nb) ? cb[j0 + threadIdx.x - 16] : 0;
+    __syncthreads();
+    int64_t i = i0 + ty, j = j0 + tx;
+    if (i < na && j < nb) {
+        double v = 0.0;
+        if (!(ca && cb) || sca[ty] == scb[tx]) v = poly_iou(&sa[ty * 8], &sb[tx * 8]);
+        out[i * nb + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stable descending rank sort
+
+__device__ __forceinline__ double sort_key(double k) { return isnan(k) ? -INFINITY : k; }
+
+// order[rank(i)] = i, rank(i) = #{j: key_j > key_i} + #{j < i: key_j == key_i}  (stable, descending)
+__global__ __launch_bounds__(256) void k_rank_sort(const double *__restrict__ key, int64_t n, int32_t *__restrict__ order) {
+    __shared__ double sk[1024];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double ki = (i < n) ? sort_key(key[i]) : 0.0;
+    int32_t rank = 0;
+    for (int64_t j0 = 0; j0 < n; j0 += 1024) {
+        int cnt = (int)((n - j0) < 1024 ? (n - j0) : 1024);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += 256) sk[t] = sort_key(key[j0 + t]);
+        __syncthreads();
+        if (i < n) {
+            for (int t = 0; t < cnt; ++t) {
+                double kj = sk[t];
+                rank += (kj > ki) | ((kj == ki) & (j0 + t < i));
+            }
+        }
+    }
+    if (i < n) order[rank] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------------ dense NMS (n > kSegMax)
+
+struct BoxMeta { double x0, y0, x1, y1; };  // envelope; invalid quads get an empty envelope (x0 > x1)
+
+// gather into sorted order + envelope/validity precompute
+__global__ __launch_bounds__(256) void k_prep_sorted(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                    const int32_t *__restrict__ order, int64_t n,
+                                                    double *__restrict__ sboxes, int32_t *__restrict__ scls,
+                                                    BoxMeta *__restrict__ meta) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t src = order ? order[i] : i;
+    P2 p[4];
+    for (int k = 0; k < 4; ++k) { p[k].x = boxes[src * 8 + 2 * k]; p[k].y = boxes[src * 8 + 2 * k + 1]; }
+    if (sboxes)
+        for (int k = 0; k < 4; ++k) { sboxes[i * 8 + 2 * k] = p[k].x; sboxes[i * 8 + 2 * k + 1] = p[k].y; }
+    if (scls) scls[i] = cls[src];
+    BoxMeta m;
+    if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+    else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
+    meta[i] = m;
+}
+
+__device__ __forceinline__ bool meta_overlap(const BoxMeta &a, const BoxMeta &b) {
+    // both valid (x0 <= x1) and envelopes not strictly disjoint
+    return a.x0 <= a.x1 && b.x0 <= b.x1 && !(a.x1 < b.x0 || b.x1 < a.x0 || a.y1 < b.y0 || b.y1 < a.y0);
+}
+
+// One wave per 64x64 block of the (row i, col j>i) pair matrix.  Phase 1: every lane runs the 64 cheap
+// class+envelope tests of its row.  Phase 2: the surviving pairs are compacted through LDS and clipped one per lane.
+// Output word layout is column-block-major: word (row i, block jb) lives at mask[jb * n + i] so that both this
+// kernel's stores and the scan kernel's loads are 512 B contiguous per wave.
+__global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sboxes, const int32_t *__restrict__ scls,
+                                                const BoxMeta *__restrict__ meta, int64_t n, double thr,
+                                                unsigned long long *__restrict__ mask) {
+    int jb = blockIdx.x, ib = blockIdx.y;
+    if (jb < ib) return;
+    __shared__ BoxMeta cm[64];
+    __shared__ int32_t cc[64];
+    __shared__ unsigned long long bits[64];
+    __shared__ unsigned short plist[4096];
+    int lane = threadIdx.x;
+    int64_t i = (int64_t)ib * 64 + lane, j = (int64_t)jb * 64 + lane;
+    BoxMeta rm;
+    int32_t rc = -1;
+    if (i < n) { rm = meta[i]; rc = scls[i]; } else { rm.x0 = 1.0; rm.x1 = -1.0; rm.y0 = rm.y1 = 0.0; }
+    if (j < n) { cm[lane] = meta[j]; cc[lane] = scls[j]; } else { cm[lane].x0 = 1.0; cm[lane].x1 = -1.0; cm[lane].y0 = cm[lane].y1 = 0.0; cc[lane] = -2; }
+    bits[lane] = 0ull;
+    __syncthreads();
+    unsigned long long cand = 0ull, direct = 0ull;
+    bool all_hit = !(thr > 0.0);  // IoU >= thr holds for every same-class pair when thr <= 0 (IoU is never negative)
+    for (int c = 0; c < 64; ++c) {
+        int64_t jj = (int64_t)jb * 64 + c;
+        bool upper = (jj > i) && (jj < n) && (i < n);
+        bool same = upper && (cc[c] == rc);
+        if (all_hit) direct |= (unsigned long long)same << c;
+        else cand |= (unsigned long long)(same && meta_overlap(rm, cm[c])) << c;
+    }
+    // wave-wide exclusive prefix of popcounts -> compact (row, col) list
+    int cnt = __popcll(cand);
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    int total = __shfl(incl, 63);
+    int pos = incl - cnt;
+    unsigned long long cw = cand;
+    while (cw) {
+        int c = __ffsll((long long)cw) - 1;
+        cw &= cw - 1;
+        plist[pos++] = (unsigned short)((lane << 6) | c);
+    }
+    __syncthreads();
+    for (int base = 0; base < total; base += 64) {
+        int t = base + lane;
+        if (t < total) {
+            int r = plist[t] >> 6, c = plist[t] & 63;
+            const double *pa = sboxes + ((int64_t)ib * 64 + r) * 8;
+            const double *pb = sboxes + ((int64_t)jb * 64 + c) * 8;
+            P2 p[4], q[4];
+            for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
+            double iou = poly_iou_core(p, q);
+            if (iou >= thr) atomicOr(&bits[r], 1ull << c);
+        }
+    }
+    __syncthreads();
+    if (i < n) mask[(int64_t)jb * n + i] = bits[lane] | direct;
+}
+
+// Greedy scan (single workgroup, 1024 threads = 16 waves).  Chunk rb of 64 rows: wave 0 resolves the diagonal block
+// serially with scalar ops, then all waves OR the kept rows' words into `removed` for the later column blocks.
+__global__ __launch_bounds__(1024) void k_nms_reduce(const unsigned long long *__restrict__ mask, int64_t n,
+                                                    uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep) {
+    extern __shared__ unsigned long long removed[];  // W words
+    __shared__ unsigned long long keepmask_s;
+    __shared__ int total_s;
+    int W = (int)((n + 63) / 64);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = threadIdx.x; w < W; w += 1024) removed[w] = 0ull;
+    if (threadIdx.x == 0) total_s = 0;
+    __syncthreads();
+    for (int rb = 0; rb < W; ++rb) {
+        if (wave == 0) {
+            int64_t i = (int64_t)rb * 64 + lane;
+            unsigned long long d = (i < n) ? mask[(int64_t)rb * n + i] : 0ull;
+            unsigned long long rem = removed[rb];
+            int nvalid = (int)((n - (int64_t)rb * 64) < 64 ? (n - (int64_t)rb * 64) : 64);
+            unsigned long long km = 0ull;
+            for (int r = 0; r < nvalid; ++r) {
+                unsigned long long dr = __shfl(d, r);  // wave-uniform
+                if (!((rem >> r) & 1ull)) { km |= 1ull << r; rem |= dr; }
+            }
+            if (i < n) keep[i] = (uint8_t)((km >> lane) & 1ull);
+            if (lane == 0) { keepmask_s = km; total_s += __popcll(km); }
+        }
+        __syncthreads();
+        unsigned long long km = keepmask_s;
+        for (int cb = rb + 1 + wave; cb < W; cb += 16) {
+            int64_t i = (int64_t)rb * 64 + lane;
+            unsigned long long w = (i < n && ((km >> lane) & 1ull)) ? mask[(int64_t)cb * n + i] : 0ull;
+            for (int d = 32; d >= 1; d >>= 1) w |= __shfl_xor(w, d);
+            if (lane == 0) removed[cb] |= w;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && n_keep) *n_keep = total_s;
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-resident segments (n <= kSegMax)
+
+static constexpr int kSegMax = 512;
+static constexpr int kSegWords = kSegMax / 64;
+
+// One workgroup per segment: rank sort, pair tests, greedy scan -- everything in LDS.
+__global__ __launch_bounds__(256) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                       const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
+                                                       double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
+                                                       int32_t *__restrict__ n_keep, int32_t *__restrict__ status) {
+    __shared__ double skey[kSegMax];
+    __shared__ int32_t sord[kSegMax];
+    __shared__ int32_t scl[kSegMax];
+    __shared__ BoxMeta smeta[kSegMax];
+    __shared__ unsigned long long sbits[kSegMax * kSegWords];
+    int seg = blockIdx.x;
+    int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    int n = s1 - s0;
+    if (n <= 0) { if (threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }
+    if (n > kSegMax) {  // caller promised max_seg_len <= kSegMax; flag and leave outputs untouched
+        if (threadIdx.x == 0) atomicExch(status, 1);
+        return;
+    }
+    for (int t = threadIdx.x; t < n; t += 256) skey[t] = sort_key(conf[s0 + t]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += 256) {
+        double ki = skey[t];
+        int rank = 0;
+        for (int u = 0; u < n; ++u) rank += (skey[u] > ki) | ((skey[u] == ki) & (u < t));
+        sord[rank] = t;
+    }
+    __syncthreads();
+    int W = (n + 63) / 64;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        int src = s0 + sord[t];
+        order[s0 + t] = src;
+        P2 p[4];
+        for (int k = 0; k < 4; ++k) { p[k].x = boxes[(int64_t)src * 8 + 2 * k]; p[k].y = boxes[(int64_t)src * 8 + 2 * k + 1]; }
+        BoxMeta m;
+        if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+        else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
+        smeta[t] = m;
+        scl[t] = cls[src];
+        for (int w = 0; w < W; ++w) sbits[t * kSegWords + w] = 0ull;
+    }
+    __syncthreads();
+    bool all_hit = !(thr > 0.0);
+    // pair (i, j>i): flatten rows over threads; rows are short so a strided row loop balances well enough
+    for (int i = threadIdx.x; i < n; i += 256) {
+        BoxMeta rm = smeta[i];
+        int rc = scl[i];
+        const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8;
+        P2 p[4];
+        bool loaded = false;
+        for (int j = i + 1; j < n; ++j) {
+            if (scl[j] != rc) continue;
+            bool hit = all_hit;
+            if (!all_hit && meta_overlap(rm, smeta[j])) {
+                if (!loaded) { for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; } loaded = true; }
+                const double *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
+                P2 q[4];
+                for (int k = 0; k < 4; ++k) { q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
+                hit = poly_iou_core(p, q) >= thr;
+            }
+            if (hit) sbits[i * kSegWords + (j >> 6)] |= 1ull << (j & 63);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: lane w owns word w of `removed`
+        int lane = threadIdx.x;
+        unsigned long long rem = 0ull;
+        int kept = 0;
+        for (int i = 0; i < n; ++i) {
+            unsigned long long wv = __shfl(rem, i >> 6);
+            bool k = !((wv >> (i & 63)) & 1ull);  // wave-uniform
+            if (k) {
+                if (lane < W) rem |= sbits[i * kSegWords + lane];
+                ++kept;
+            }
+            if (lane == 0) keep[s0 + i] = (uint8_t)k;
+        }
+        if (lane == 0 && n_keep) n_keep[seg] = kept;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ consensus (single workgroup)
+
+__global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                  const double *__restrict__ conf, const int64_t *__restrict__ off,
+                                                  int32_t nscales, double iou_partner, double cons_low, double cons_high,
+                                                  uint8_t *__restrict__ state /* [total]: bit0 alive, bit1 visited */,
+                                                  BoxMeta *__restrict__ meta, int32_t *__restrict__ out_idx,
+                                                  int32_t *__restrict__ n_out) {
+    __shared__ double r_conf[256], r_iou[256];
+    __shared__ int32_t r_idx[256];
+    __shared__ int32_t nout_s;
+    int64_t total = off[nscales];
+    int tid = threadIdx.x;
+    if (tid == 0) nout_s = 0;
+    if (nscales == 1) {  // Detect_OBB.py:357-358 passthrough
+        for (int64_t i = tid; i < total; i += 256) out_idx[i] = (int32_t)i;
+        if (tid == 0) *n_out = (int32_t)total;
+        return;
+    }
+    for (int64_t i = tid; i < total; i += 256) {
+        state[i] = (conf[i] >= cons_low) ? 1 : 0;  // :361-364
+        P2 p[4];
+        for (int k = 0; k < 4; ++k) { p[k].x = boxes[i * 8 + 2 * k]; p[k].y = boxes[i * 8 + 2 * k + 1]; }
+        BoxMeta m;
+        if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+        else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
+        meta[i] = m;
+    }
+    __syncthreads();
+    for (int32_t s = 0; s < nscales; ++s) {
+        for (int64_t i = off[s]; i < off[s + 1]; ++i) {
+            if (state[i] != 1) continue;  // not alive or already visited (uniform: every thread reads the same byte)
+            int ci = cls[i];
+            BoxMeta mi = meta[i];
+            P2 p[4];
+            for (int k = 0; k < 4; ++k) { p[k].x = boxes[i * 8 + 2 * k]; p[k].y = boxes[i * 8 + 2 * k + 1]; }
+            double bc = -1.0, bi = 0.0;
+            int32_t bj = -1;
+            for (int64_t j = tid; j < total; j += 256) {
+                if (j >= off[s] && j < off[s + 1]) continue;  // same scale
+                if (state[j] != 1 || cls[j] != ci) continue;
+                double iou = 0.0;
+                if (meta_overlap(mi, meta[j])) {
+                    P2 q[4];
+                    for (int k = 0; k < 4; ++k) { q[k].x = boxes[j * 8 + 2 * k]; q[k].y = boxes[j * 8 + 2 * k + 1]; }
+                    iou = poly_iou_core(p, q);
+                }
+                if (iou >= iou_partner) {
+                    double cp = conf[j];
+                    // thread-local scan is in ascending j: strict improvements only (Detect_OBB.py:397-399)
+                    if (cp > bc || (cp == bc && iou > bi)) { bc = cp; bi = iou; bj = (int32_t)j; }
+                }
+            }
+            r_conf[tid] = bc; r_iou[tid] = bi; r_idx[tid] = bj;
+            __syncthreads();
+            for (int d = 128; d >= 1; d >>= 1) {
+                if (tid < d) {
+                    double c2 = r_conf[tid + d], i2 = r_iou[tid + d];
+                    int32_t j2 = r_idx[tid + d];
+                    double c1 = r_conf[tid], i1 = r_iou[tid];
+                    int32_t j1 = r_idx[tid];
+                    // prefer higher conf, then higher iou, then the earlier pool position (first encountered wins ties)
+                    bool take2 = (j2 >= 0) && (j1 < 0 || c2 > c1 || (c2 == c1 && (i2 > i1 || (i2 == i1 && j2 < j1))));
+                    if (take2) { r_conf[tid] = c2; r_iou[tid] = i2; r_idx[tid] = j2; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                int32_t best = r_idx[0];
+                double bconf = r_conf[0];
+                if (best < 0 || bconf < cons_low) {  // :406-410
+                    if (conf[i] >= cons_high) out_idx[nout_s++] = (int32_t)i;
+                    state[i] = 3;
+                } else {  // :412-421
+                    out_idx[nout_s++] = (conf[i] >= bconf) ? (int32_t)i : best;
+                    state[i] = 3;
+                    state[best] = 3;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) *n_out = nout_s;
+}
+
+// ------------------------------------------------------------------------------------------------ detect_symbols per-detection body
+
+__global__ __launch_bounds__(256) void k_tile_post(const float *__restrict__ lp, const int32_t *__restrict__ cls,
+                                                  const int32_t *__restrict__ det_tile, int64_t n,
+                                                  const int32_t *__restrict__ rects, int32_t margin, int32_t strike_cls,
+                                                  double *__restrict__ gb, double *__restrict__ angle,
+                                                  uint8_t *__restrict__ inside) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int t = det_tile[i];
+    int x = rects[4 * t], y = rects[4 * t + 1], x2 = rects[4 * t + 2], y2 = rects[4 * t + 3];
+    double p[8], g[8];
+    for (int k = 0; k < 8; ++k) p[k] = (double)lp[i * 8 + k];  // float(v) widening, Detect_OBB.py:229
+    for (int k = 0; k < 4; ++k) { g[2 * k] = p[2 * k] + (double)x; g[2 * k + 1] = p[2 * k + 1] + (double)y; }  // :233-234
+    for (int k = 0; k < 8; ++k) gb[i * 8 + k] = g[k];
+    double cx = (g[0] + g[2] + g[4] + g[6]) / 4.0, cy = (g[1] + g[3] + g[5] + g[7]) / 4.0;  // :163-164
+    double cxr = cx - (double)x, cyr = cy - (double)y, m = (double)margin;
+    double cw = (double)(x2 - x), ch = (double)(y2 - y);
+    bool in = true;
+    if (margin > 0) in = (m <= cxr && cxr <= (cw - m)) && (m <= cyr && cyr <= (ch - m));  // :174, :242
+    inside[i] = (uint8_t)in;
+    double a = 0.0;
+    if (cls[i] == strike_cls) {  // :251-254 uses the LOCAL points
+        a = atan2(p[6] - p[0], p[7] - p[1]) * (180.0 / 3.141592653589793);
+        a = (a > 0) ? 180 - a : fabs(a);
+    }
+    angle[i] = a;
+}
+
+}  // namespace obb
+
+using namespace obb;
+
+extern "C" {
+
+int obb_poly_iou_pairs(obb_ctx *ctx, const double *a, const double *b, int64_t m, double *out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && m >= 0, "obb_poly_iou_pairs: bad arguments");
+    if (m == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, a && b && out, "obb_poly_iou_pairs: NULL buffer");
+    hipLaunchKernelGGL(k_iou_pairs, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, (hipStream_t)s, a, b, m, out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int64_t na, const double *b,
+                        const int32_t *cls_b, int64_t nb, double *out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && na >= 0 && nb >= 0, "obb_poly_iou_matrix: bad arguments");
+    if (na == 0 || nb == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, a && b && out, "obb_poly_iou_matrix: NULL buffer");
+    OBB_REQUIRE(ctx, cdiv(na, 16) <= 65535, "obb_poly_iou_matrix: na too large (%lld)", (long long)na);
+    hipLaunchKernelGGL(k_iou_matrix, dim3((unsigned)cdiv(nb, 16), (unsigned)cdiv(na, 16)), dim3(256), 0, (hipStream_t)s, a,
+                       cls_a, na, b, cls_b, nb, out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *order, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1ll << 31), "obb_sort_desc_stable: bad n");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, key && order, "obb_sort_desc_stable: NULL buffer");
+    hipLaunchKernelGGL(k_rank_sort, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, key, n, order);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+static int nms_mask_impl(obb_ctx *ctx, const double *sboxes, const int32_t *scls, const BoxMeta *meta, int64_t n, double thr,
+                         uint64_t *mask, hipStream_t st) {
+    int64_t W = cdiv(n, 64);
+    OBB_REQUIRE(ctx, W <= 65535, "nms: n=%lld exceeds the 4.19M-box grid limit", (long long)n);
+    hipLaunchKernelGGL(k_nms_mask, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, sboxes, scls, meta, n, thr,
+                       (unsigned long long *)mask);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_nms_mask(obb_ctx *ctx, const double *boxes_sorted, const int32_t *cls_sorted, int64_t n, double thr, uint64_t *mask,
+                 obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_nms_mask: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, boxes_sorted && cls_sorted && mask, "obb_nms_mask: NULL buffer");
+    BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)n);
+    if (!meta) return set_error(ctx, OBB_ERR_HIP, "obb_nms_mask: workspace allocation failed");
+    hipLaunchKernelGGL(k_prep_sorted, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, boxes_sorted, cls_sorted,
+                       (const int32_t *)nullptr, n, (double *)nullptr, (int32_t *)nullptr, meta);
+    OBB_LAUNCH_CHECK(ctx);
+    return nms_mask_impl(ctx, boxes_sorted, cls_sorted, meta, n, thr, mask, (hipStream_t)s);
+}
+
+int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep, int32_t *n_keep, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_nms_reduce: bad arguments");
+    if (n == 0) {
+        if (n_keep) OBB_HIP(ctx, hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)s));
+        return OBB_OK;
+    }
+    OBB_REQUIRE(ctx, mask && keep, "obb_nms_reduce: NULL buffer");
+    size_t lds = sizeof(unsigned long long) * (size_t)cdiv(n, 64);
+    OBB_REQUIRE(ctx, lds <= 128 * 1024, "obb_nms_reduce: n=%lld too large for the LDS-resident scan (max 1M boxes)", (long long)n);
+    hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(1024), lds, (hipStream_t)s, (const unsigned long long *)mask, n, keep, n_keep);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int32_t *seg_off,
+                       int32_t nseg, int64_t n, double thr, int32_t *order, uint8_t *keep, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && nseg >= 0 && n >= 0, "obb_merge_segments: bad arguments");
+    if (nseg == 0 || n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, boxes && cls && conf && seg_off && order && keep, "obb_merge_segments: NULL buffer");
+    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
+    if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
+    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), (hipStream_t)s));
+    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(256), 0, (hipStream_t)s, boxes, cls, conf, seg_off, thr,
+                       order, keep, (int32_t *)nullptr, status);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n, double thr,
+                         int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1ll << 31), "obb_merge_detections: bad n");
+    hipStream_t st = (hipStream_t)s;
+    if (n == 0) {
+        if (n_keep) OBB_HIP(ctx, hipMemsetAsync(n_keep, 0, sizeof(int32_t), st));
+        return OBB_OK;
+    }
+    OBB_REQUIRE(ctx, boxes && cls && conf && order && keep, "obb_merge_detections: NULL buffer");
+    if (n <= kSegMax) {
+        int32_t *segoff = (int32_t *)ctx->workspace(WS_GEOM_D, 256);
+        int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
+        if (!segoff || !status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+        int32_t h[2] = {0, (int32_t)n};
+        OBB_HIP(ctx, hipMemcpyAsync(segoff, h, sizeof h, hipMemcpyHostToDevice, st));
+        OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(256), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status);
+        OBB_LAUNCH_CHECK(ctx);
+        return OBB_OK;
+    }
+    int64_t W = cdiv(n, 64);
+    double *sboxes = (double *)ctx->workspace(WS_GEOM_A, sizeof(double) * 8 * (size_t)n);
+    int32_t *scls = (int32_t *)ctx->workspace(WS_GEOM_B, sizeof(int32_t) * (size_t)n);
+    BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)n);
+    uint64_t *mask = (uint64_t *)ctx->workspace(WS_NMS_B, sizeof(uint64_t) * (size_t)(W * n));
+    if (!sboxes || !scls || !meta || !mask) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+    int rc = obb_sort_desc_stable(ctx, conf, n, order, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_prep_sorted, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, boxes, cls, (const int32_t *)order, n, sboxes,
+                       scls, meta);
+    OBB_LAUNCH_CHECK(ctx);
+    rc = nms_mask_impl(ctx, sboxes, scls, meta, n, thr, mask, st);
+    if (rc) return rc;
+    return obb_nms_reduce(ctx, mask, n, keep, n_keep, s);
+}
+
+int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int64_t *off_host,
+                  int32_t nscales, double iou_partner, double cons_low, double cons_high, int32_t *out_idx, int32_t *n_out,
+                  obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && off_host && nscales >= 1 && nscales <= 16 && n_out, "obb_consensus: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    int64_t total = off_host[nscales];
+    for (int k = 0; k < nscales; ++k) OBB_REQUIRE(ctx, off_host[k] <= off_host[k + 1], "obb_consensus: offsets must ascend");
+    if (total == 0) { OBB_HIP(ctx, hipMemsetAsync(n_out, 0, sizeof(int32_t), st)); return OBB_OK; }
+    OBB_REQUIRE(ctx, boxes && cls && conf && out_idx, "obb_consensus: NULL buffer");
+    int64_t *off = (int64_t *)ctx->workspace(WS_GEOM_D, 256);
+    uint8_t *state = (uint8_t *)ctx->workspace(WS_GEOM_C, (size_t)total);
+    BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)total);
+    if (!off || !state || !meta) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
+    OBB_HIP(ctx, hipMemcpyAsync(off, off_host, sizeof(int64_t) * (nscales + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner,
+                       cons_low, cons_high, state, meta, out_idx, n_out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_tile_grid(int32_t H, int32_t W, int32_t tile, int32_t overlap, int32_t *rects_host, int64_t max_tiles, int64_t *n_tiles) {
+    if (H < 0 || W < 0 || tile <= 0 || !n_tiles) return set_error(nullptr, OBB_ERR_INVALID, "obb_tile_grid: bad arguments");
+    int32_t step = tile - overlap;
+    if (step < 1) step = 1;  // Detect_OBB.py:211
+    int64_t n = 0;
+    for (int32_t y = 0; y < H; y += step)
+        for (int32_t x = 0; x < W; x += step) {
+            int32_t y2 = y + tile < H ? y + tile : H, x2 = x + tile < W ? x + tile : W;
+            if (y2 - y == 0 || x2 - x == 0) continue;  // :222
+            if (rects_host && n < max_tiles) { rects_host[4 * n] = x; rects_host[4 * n + 1] = y; rects_host[4 * n + 2] = x2; rects_host[4 * n + 3] = y2; }
+            ++n;
+        }
+    *n_tiles = n;
+    return OBB_OK;
+}
+
+int obb_tile_postprocess(obb_ctx *ctx, const float *local_pts, const int32_t *cls, const int32_t *det_tile, int64_t n,
+                         const int32_t *rects, int32_t ntiles, int32_t margin, int32_t strike_cls, double *gboxes, double *angle,
+                         uint8_t *inside, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && ntiles >= 0, "obb_tile_postprocess: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, local_pts && cls && det_tile && rects && gboxes && angle && inside, "obb_tile_postprocess: NULL buffer");
+    hipLaunchKernelGGL(k_tile_post, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, local_pts, cls, det_tile, n, rects,
+                       margin, strike_cls, gboxes, angle, inside);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""Tensor-level bindings of the C-ABI: torch tensors supply device memory and the current HIP stream, nothing else.
+
+Every function here launches hand-written HIP kernels from libobbhip.so; inputs must be CUDA(=HIP) tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_ctx = {}
+
+
+def ctx(device=None):
+    """One library context per device (created lazily)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if idx not in _ctx:
+        h = C.c_void_p()
+        _lib.check(_lib.lib().obb_ctx_create(idx, C.byref(h)))
+        _ctx[idx] = h
+    return _ctx[idx]
+
+
+def destroy_contexts():
+    for h in _ctx.values():
+        _lib.lib().obb_ctx_destroy(h)
+    _ctx.clear()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/HIP tensor (there is no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def _call(name, c, *args):
+    _lib.check(getattr(_lib.lib(), name)(c, *args), c)
+
+
+# ---------------------------------------------------------------- S2 polygon IoU
+
+def poly_iou_pairs(a, b):
+    """a, b: [M,8] float64 -> [M] float64   (compute_polygon_iou per row, Detect_OBB.py:144)"""
+    a = _chk(a, torch.float64, "a").reshape(-1, 8)
+    b = _chk(b, torch.float64, "b").reshape(-1, 8)
+    if a.shape != b.shape:
+        raise ValueError("poly_iou_pairs: shape mismatch")
+    out = torch.empty(a.shape[0], dtype=torch.float64, device=a.device)
+    _call("obb_poly_iou_pairs", ctx(a.device), _p(a), _p(b), a.shape[0], _p(out), _stream())
+    return out
+
+
+def poly_iou_matrix(a, b, cls_a=None, cls_b=None):
+    a = _chk(a, torch.float64, "a").reshape(-1, 8)
+    b = _chk(b, torch.float64, "b").reshape(-1, 8)
+    if cls_a is not None:
+        _chk(cls_a, torch.int32, "cls_a")
+        _chk(cls_b, torch.int32, "cls_b")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
+    _call("obb_poly_iou_matrix", ctx(a.device), _p(a), _p(cls_a), a.shape[0], _p(b), _p(cls_b), b.shape[0], _p(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- S3 merge_detections
+
+def sort_desc_stable(key):
+    key = _chk(key, torch.float64, "key")
+    order = torch.empty(key.shape[0], dtype=torch.int32, device=key.device)
+    _call("obb_sort_desc_stable", ctx(key.device), _p(key), key.shape[0], _p(order), _stream())
+    return order
+
+
+def nms_mask(boxes_sorted, cls_sorted, thr):
+    b = _chk(boxes_sorted, torch.float64, "boxes").reshape(-1, 8)
+    c = _chk(cls_sorted, torch.int32, "cls")
+    n = b.shape[0]
+    w = (n + 63) // 64
+    mask = torch.zeros((w, max(n, 1)), dtype=torch.int64, device=b.device)
+    _call("obb_nms_mask", ctx(b.device), _p(b), _p(c), n, float(thr), _p(mask), _stream())
+    return mask
+
+
+def nms_reduce(mask, n):
+    keep = torch.zeros(n, dtype=torch.uint8, device=mask.device)
+    nk = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    _call("obb_nms_reduce", ctx(mask.device), _p(mask), n, _p(keep), _p(nk), _stream())
+    return keep, nk
+
+
+def merge_detections(boxes, cls, conf, thr):
+    """-> (order int32[n]: sorted position -> input row, keep uint8[n] in sorted order, n_keep int32[1])"""
+    b = _chk(boxes, torch.float64, "boxes").reshape(-1, 8)
+    c = _chk(cls, torch.int32, "cls")
+    s = _chk(conf, torch.float64, "conf")
+    n = b.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=b.device)
+    keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
+    nk = torch.zeros(1, dtype=torch.int32, device=b.device)
+    _call("obb_merge_detections", ctx(b.device), _p(b), _p(c), _p(s), n, float(thr), _p(order), _p(keep), _p(nk), _stream())
+    return order, keep, nk
+
+
+def merge_segments(boxes, cls, conf, seg_off, thr):
+    """Batched per-tile merge (Detect_OBB.py:264).  seg_off int32[nseg+1] device.  Segments must be <= 512 rows."""
+    b = _chk(boxes, torch.float64, "boxes").reshape(-1, 8)
+    c = _chk(cls, torch.int32, "cls")
+    s = _chk(conf, torch.float64, "conf")
+    so = _chk(seg_off, torch.int32, "seg_off")
+    n = b.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=b.device)
+    keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
+    _call("obb_merge_segments", ctx(b.device), _p(b), _p(c), _p(s), _p(so), so.shape[0] - 1, n, float(thr), _p(order), _p(keep),
+          _stream())
+    return order, keep
+
+
+# ---------------------------------------------------------------- S4 consensus
+
+def consensus(boxes, cls, conf, offsets, iou_partner=0.40, cons_low=0.25, cons_high=0.70):
+    b = _chk(boxes, torch.float64, "boxes").reshape(-1, 8)
+    c = _chk(cls, torch.int32, "cls")
+    s = _chk(conf, torch.float64, "conf")
+    off = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
+    out = torch.empty(max(1, b.shape[0]), dtype=torch.int32, device=b.device)
+    nout = torch.zeros(1, dtype=torch.int32, device=b.device)
+    _call("obb_consensus", ctx(b.device), _p(b), _p(c), _p(s), off, len(offsets) - 1, float(iou_partner), float(cons_low),
+          float(cons_high), _p(out), _p(nout), _stream())
+    return out, nout
+
+
+# ---------------------------------------------------------------- S5 detect_symbols pieces
+
+def tile_grid(H, W, tile, overlap):
+    """Host helper -> int32 numpy [ntiles,4] (x, y, x2, y2) in reference visiting order."""
+    import numpy as np
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().obb_tile_grid(H, W, tile, overlap, None, 0, C.byref(n)))
+    rects = np.zeros((max(1, n.value), 4), np.int32)
+    _lib.check(_lib.lib().obb_tile_grid(H, W, tile, overlap, rects.ctypes.data_as(_lib.c_ip), n.value, C.byref(n)))
+    return rects[:n.value]
+
+
+def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
+    lp = _chk(local_pts, torch.float32, "local_pts").reshape(-1, 8)
+    c = _chk(cls, torch.int32, "cls")
+    dt = _chk(det_tile, torch.int32, "det_tile")
+    r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
+    n = lp.shape[0]
+    gb = torch.empty((n, 8), dtype=torch.float64, device=lp.device)
+    ang = torch.empty(n, dtype=torch.float64, device=lp.device)
+    ins = torch.empty(n, dtype=torch.uint8, device=lp.device)
+    _call("obb_tile_postprocess", ctx(lp.device), _p(lp), _p(c), _p(dt), n, _p(r), r.shape[0], int(margin), int(strike_cls),
+          _p(gb), _p(ang), _p(ins), _stream())
+    return gb, ang, ins

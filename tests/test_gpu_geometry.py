@@ -1,0 +1,192 @@
+"""GPU parity: HIP geometry kernels (through the C-ABI) vs the CPU oracle and the reference-generated goldens.
+Bit-exact for keep masks / orders / indices and for fp64 IoU values (same op order, -ffp-contract=off both sides)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CLASS_IDS, GOLDEN, load_xlsx_csv
+from oracle import geom as og
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import ops as o
+    return o
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def test_iou_pairs_bit_exact(ops):
+    boxes, cls, conf, _ = synth.make_dets(123, 20000, extent=900.0)
+    rng = np.random.default_rng(5)
+    a = boxes
+    b = boxes[rng.permutation(len(boxes))]
+    b[:5000] = a[:5000] + rng.normal(0, 3.0, (5000, 1))  # guaranteed heavy overlaps
+    b[5000:5010] = a[5000:5010]  # identical
+    a[6000] = [0, 0, 1, 1, 1, 0, 0, 1]  # bow-tie -> 0
+    a[6001] = np.nan
+    exp = og.poly_iou_pairs(a, b)
+    got = ops.poly_iou_pairs(dev(a, torch.float64), dev(b, torch.float64)).cpu().numpy()
+    assert (exp > 0.3).sum() > 1000
+    assert np.array_equal(got, exp)
+    assert got[6000] == 0.0 and got[6001] == 0.0 and np.all(got[5000:5010] == 1.0)
+
+
+def test_iou_pairs_empty_and_ragged(ops):
+    e = torch.zeros((0, 8), dtype=torch.float64, device="cuda")
+    assert ops.poly_iou_pairs(e, e).numel() == 0
+    for m in (1, 63, 64, 65, 255, 257):
+        boxes, _, _, _ = synth.make_dets(m, 2 * m, extent=120.0)
+        a, b = boxes[:m], boxes[m:]
+        assert np.array_equal(ops.poly_iou_pairs(dev(a, torch.float64), dev(b, torch.float64)).cpu().numpy(), og.poly_iou_pairs(a, b))
+
+
+def test_iou_matrix(ops):
+    b1, c1, _, _ = synth.make_dets(1, 150, extent=300.0)
+    b2, c2, _, _ = synth.make_dets(2, 77, extent=300.0)
+    got = ops.poly_iou_matrix(dev(b1, torch.float64), dev(b2, torch.float64), dev(c1, torch.int32), dev(c2, torch.int32)).cpu().numpy()
+    exp = np.zeros((150, 77))
+    for i in range(150):
+        for j in range(77):
+            if c1[i] == c2[j]:
+                exp[i, j] = og.compute_polygon_iou(b1[i], b2[j])
+    assert np.array_equal(got, exp)
+    got2 = ops.poly_iou_matrix(dev(b1, torch.float64), dev(b2, torch.float64)).cpu().numpy()
+    assert got2[3, 5] == og.compute_polygon_iou(b1[3], b2[5])
+
+
+def test_sort_desc_stable(ops):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 100, 1024, 1025, 5000):
+        k = rng.uniform(0, 1, n).astype(np.float32).astype(np.float64)
+        k[rng.integers(0, n, n // 4 + 1)] = k[0]  # ties
+        got = ops.sort_desc_stable(dev(k, torch.float64)).cpu().numpy()
+        assert np.array_equal(got, og.sort_desc_stable(k))
+        assert np.array_equal(got, np.argsort(-k, kind="stable"))
+
+
+def test_merge_matches_reference_goldens(ops, ref_vectors):
+    rv = ref_vectors
+    for ci in rv["merge_cases"]:
+        boxes, cls, conf = rv[f"merge{ci}_boxes"].reshape(-1, 8), rv[f"merge{ci}_cls"], rv[f"merge{ci}_conf"]
+        if len(cls) == 0:
+            continue
+        order, keep, nk = ops.merge_detections(dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64), float(rv[f"merge{ci}_thr"]))
+        order, keep = order.cpu().numpy(), keep.cpu().numpy().astype(bool)
+        assert np.array_equal(order, rv[f"merge{ci}_sorted"]), f"case {ci}"
+        assert np.array_equal(order[keep], rv[f"merge{ci}_kept"]), f"case {ci}"
+        assert int(nk.item()) == len(rv[f"merge{ci}_kept"])
+
+
+@pytest.mark.parametrize("n,extent", [(513, 400.0), (4096, 1500.0), (16384, 4096.0)])
+def test_merge_dense_path_vs_oracle(ops, n, extent):
+    boxes, cls, conf, _ = synth.make_dets(1000 + n, n, extent=extent)
+    eo, ek = og.merge_arrays(boxes, cls, conf, 0.4)
+    order, keep, nk = ops.merge_detections(dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64), 0.4)
+    assert np.array_equal(order.cpu().numpy(), eo)
+    assert np.array_equal(keep.cpu().numpy(), ek)
+    assert int(nk.item()) == int(ek.sum())
+    # low-level API: mask + reduce on pre-sorted input gives the same keep flags
+    sb, sc = boxes[eo], cls[eo]
+    mask = ops.nms_mask(dev(sb, torch.float64), dev(sc, torch.int32), 0.4)
+    k2, nk2 = ops.nms_reduce(mask, n)
+    assert np.array_equal(k2.cpu().numpy(), ek)
+
+
+def test_merge_idempotent_at_scale(ops):
+    """size-independent property at a size the oracle is too slow for: merging the survivors again changes nothing."""
+    n = 65536
+    boxes, cls, conf, _ = synth.make_dets(7, n, extent=8192.0)
+    B, Cc, S = dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64)
+    order, keep, nk = ops.merge_detections(B, Cc, S, 0.4)
+    sel = order[keep.bool()].long()
+    assert len(sel) == int(nk.item()) and 0 < len(sel) < n
+    o2, k2, nk2 = ops.merge_detections(B[sel].contiguous(), Cc[sel].contiguous(), S[sel].contiguous(), 0.4)
+    assert bool(k2.all()) and int(nk2.item()) == len(sel)
+    assert np.array_equal(o2.cpu().numpy(), np.arange(len(sel)))  # already conf-sorted
+    srt = S[order.long()].cpu().numpy()
+    assert np.all(np.diff(srt) <= 0)
+
+
+def test_merge_segments_vs_oracle(ops):
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 5, 300, 0, 64, 65, 512, 17]
+    bs, cs, ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        b, c, s, _ = synth.make_dets(50 + k, n, extent=250.0) if n else (np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros(0), None)
+        bs.append(b); cs.append(c); ss.append(s); off.append(off[-1] + n)
+    B, Cc, S = np.concatenate(bs), np.concatenate(cs), np.concatenate(ss)
+    order, keep = ops.merge_segments(dev(B, torch.float64), dev(Cc, torch.int32), dev(S, torch.float64), dev(np.array(off), torch.int32), 0.4)
+    order, keep = order.cpu().numpy(), keep.cpu().numpy()
+    for k, n in enumerate(sizes):
+        if n == 0:
+            continue
+        eo, ek = og.merge_arrays(bs[k], cs[k], ss[k], 0.4)
+        assert np.array_equal(order[off[k]:off[k + 1]], eo + off[k]), k
+        assert np.array_equal(keep[off[k]:off[k + 1]], ek), k
+
+
+def test_consensus_matches_reference_goldens(ops, ref_vectors):
+    rv = ref_vectors
+    for ci in rv["cons_cases"]:
+        b = np.concatenate([rv[f"cons{ci}_b1"].reshape(-1, 8), rv[f"cons{ci}_b2"].reshape(-1, 8)])
+        c = np.concatenate([rv[f"cons{ci}_c1"], rv[f"cons{ci}_c2"]]).astype(np.int32)
+        s = np.concatenate([rv[f"cons{ci}_s1"], rv[f"cons{ci}_s2"]])
+        n1 = len(rv[f"cons{ci}_c1"])
+        if len(c) == 0:
+            continue
+        idx, nout = ops.consensus(dev(b, torch.float64), dev(c, torch.int32), dev(s, torch.float64), [0, n1, len(c)])
+        idx = idx.cpu().numpy()[:int(nout.item())]
+        tags = np.where(idx < n1, idx, idx - n1 + 100000)
+        assert np.array_equal(tags, rv[f"cons{ci}_kept"]), f"case {ci}"
+    ci = rv["cons_cases"][-1]
+    n2 = len(rv[f"cons{ci}_c2"])
+    idx, nout = ops.consensus(dev(rv[f"cons{ci}_b2"], torch.float64), dev(rv[f"cons{ci}_c2"], torch.int32), dev(rv[f"cons{ci}_s2"], torch.float64), [0, n2])
+    assert np.array_equal(idx.cpu().numpy()[:int(nout.item())] + 100000, rv["cons_single_kept"])
+
+
+def test_detect_symbols_body_matches_reference(ops):
+    """tile grid + per-detection body + per-tile merge == the reference's detect_symbols on the same stub model."""
+    cases = json.load(open(os.path.join(GOLDEN, "detect_symbols_cases.json")))
+    for c in cases:
+        rects = ops.tile_grid(c["H"], c["W"], c["tile"], c["overlap"])
+        assert [list(map(int, (x, y, y2 - y, x2 - x))) for (x, y, x2, y2) in rects] == c["tiles"]
+        pts, cls, conf, tid = [], [], [], []
+        for t, (x, y, x2, y2) in enumerate(rects):
+            p, cl, sc = synth.stub_local_dets(int(x), int(y), int(y2 - y), int(x2 - x), c["seed"])
+            pts.append(p); cls.append(cl); conf.append(sc); tid.append(np.full(len(cl), t, np.int32))
+        pts, cls, conf, tid = np.concatenate(pts), np.concatenate(cls), np.concatenate(conf), np.concatenate(tid)
+        margin = 10 if c["tile"] <= 128 else 20
+        gb, ang, ins = ops.tile_postprocess(dev(pts, torch.float32), dev(cls, torch.int32), dev(tid, torch.int32), dev(rects, torch.int32), margin)
+        ins = ins.bool()
+        gb, ang, cl_d, cf_d, tid_d = gb[ins], ang[ins], dev(cls, torch.int32)[ins], dev(conf, torch.float32)[ins].double(), dev(tid, torch.int32)[ins]
+        counts = torch.bincount(tid_d.long(), minlength=len(rects))
+        seg = torch.zeros(len(rects) + 1, dtype=torch.int32, device="cuda")
+        seg[1:] = torch.cumsum(counts, 0).int()
+        order, keep = ops.merge_segments(gb.contiguous(), cl_d.contiguous(), cf_d.contiguous(), seg, 0.4)
+        sel = order[keep.bool()].long()
+        got = torch.cat([gb[sel], cl_d[sel].double()[:, None], cf_d[sel][:, None], ang[sel][:, None]], 1).cpu().numpy()
+        exp = np.array(c["dets"], np.float64).reshape(-1, 11)
+        assert got.shape == exp.shape, (c["tile"], got.shape, exp.shape)
+        assert np.array_equal(got[:, :10], exp[:, :10])
+        assert np.max(np.abs(got[:, 10] - exp[:, 10]), initial=0.0) <= 1e-9  # atan2 ulp differences only
+
+
+@pytest.mark.parametrize("name", ["Test1", "Test2"])
+def test_xlsx_goldens_are_fixed_points(ops, name):
+    names, boxes, conf, angle = load_xlsx_csv(name)
+    cls = np.array([CLASS_IDS[n] for n in names], np.int32)
+    order, keep, nk = ops.merge_detections(dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64), 0.4)
+    assert np.array_equal(order.cpu().numpy(), np.arange(len(cls))) and bool(keep.all())
+    idx, nout = ops.consensus(dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64), [0, len(cls)])
+    assert np.array_equal(idx.cpu().numpy()[:int(nout.item())], np.arange(len(cls)))

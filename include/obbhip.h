@@ -53,8 +53,9 @@ int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int
 /* ------------------------------------------------------------------ S3: merge_detections  (Detect_OBB.py:176-200) */
 /* order[n] = stable descending argsort of key (Python list.sort(key=conf, reverse=True), Detect_OBB.py:183). */
 int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *order, obb_stream_t s);
-/* Pair-suppression bit matrix over boxes already in sorted order: bit j of mask[i*W + j/64] (W = ceil(n/64)) is set
- * iff j > i, cls equal and IoU(i,j) >= thr  (Detect_OBB.py:193). */
+/* Pair-suppression bit matrix over boxes already in sorted order, column-block-major: bit (j % 64) of word
+ * mask[(j / 64) * n + i] is set iff j > i, cls equal and IoU(i,j) >= thr  (Detect_OBB.py:193).
+ * mask: uint64[ceil(n/64) * n]. */
 int obb_nms_mask(obb_ctx *ctx, const double *boxes_sorted, const int32_t *cls_sorted, int64_t n, double thr,
                  uint64_t *mask, obb_stream_t s);
 /* Greedy scan of that matrix (Detect_OBB.py:186-198): keep[i] in sorted order, *n_keep = number kept. */
@@ -107,8 +108,10 @@ int obb_model_info(const obb_ctx *ctx, int32_t h, int32_t w, int32_t *nc, int32_
  * passes crops, Detect_OBB.py:93) -> raw head float[B*A*(64+nc+1)] (per anchor: 4x16 DFL logits, nc class logits,
  * 1 angle logit).  Preprocess (BGR->RGB, /255; Appendix A2) is fused into the first convolution. */
 int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s);
-/* Debug/parity tap: copy activation buffer `buf_id` of the last forward (bf16 NHWC widened to float) to out. */
-int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, int32_t buf_id, float *out, int64_t max_elems,
+/* Debug/parity tap: copy the activation called `name` (a conv's state-dict path such as "model.2.cv1", or a
+ * layer output "x0".."x22") of the last forward to out as dense float[B*H*W*C] (bf16 widened).  out may be NULL to
+ * query *n_elems / shape only. */
+int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const char *name, float *out, int64_t max_elems,
                          int64_t *n_elems, int32_t *shape_hwc_host, obb_stream_t s);
 /* Decode (DFL, dist2rbox, angle, sigmoid; Appendix A4) + conf filter + class-offset ProbIoU Fast-NMS + max_det.
  * out float[B*max_det*7] rows (x, y, w, h, conf, cls, theta) in score order; count int32[B]. */

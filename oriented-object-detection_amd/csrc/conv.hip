@@ -1,0 +1,356 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores: the OBBModel forward's Conv(+folded BN)+SiLU layers
+// (ultralytics nn/modules Conv, reached from Detect_OBB.py:81-83).
+//
+// Mapping (per workgroup = 4 waves, 256 threads):
+//   * GEMM is computed TRANSPOSED, D^T[cout][pixel] = W[cout][k] * X[k][pixel], with v_mfma_f32_16x16x32_bf16:
+//       A operand = packed weights (16 couts x 32 k), streamed straight from global/L2 in fragment order (1 KiB
+//                   contiguous per wave-instruction; the same lines are shared by the 4 waves of the group),
+//       B operand = activations (32 k x 16 pixels) read with ds_read_b128 from an LDS-staged input tile (halo included),
+//                   so the 9 taps of a 3x3 re-use one staged copy.
+//     D then has pixel = lane&15 and cout = (lane>>4)*4 + reg; the host permutes couts inside a 16*NF block so that a
+//     lane owns 4*NF CONTIGUOUS output channels of one pixel -> the NHWC store is 8*NF bytes per lane, 128 B per pixel.
+//   * k index = (tap, cin) with cin fastest, in chunks of 8 channels (one 16 B LDS read); chunk q of a stage maps to
+//     tap = q / (CK/8), c0 = 8 * (q % (CK/8)), which works for every power-of-two CK >= 8 (3x3 with 8 or 16 input
+//     channels packs several taps into one 32-deep MFMA step).  Padding k-steps carry zero weights.
+//   * waves split the pixel dimension (MF fragments of 16 pixels each); all waves share the same 16*NF couts.
+//   * epilogue fused: + bias, SiLU, + residual, bf16 (or fp32) store into a channel slice of the output buffer, so
+//     Concat / chunk never exist as kernels.
+//   * the network input layer reads the uint8 NHWC tile directly (BGR->RGB + /255 via a 256-entry LUT = exactly
+//     bf16(v/255)), i.e. the predictor's preprocess is fused into conv0.
+#include "conv.h"
+
+#include <cstring>
+
+namespace obb {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvParams {
+    const void *in; int64_t in_bs; int in_cs, in_co;
+    void *out; int64_t out_bs; int out_cs, out_co;
+    const bf16_t *res; int64_t res_bs; int res_cs, res_co;
+    const bf16_t *wpk; const float *bias; const bf16_t *lut;
+    int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
+    int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst;
+    float inv_twin, inv_tw;
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    // round-to-nearest-even via the hardware convert (keeps NaN a NaN)
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    uint16_t ux, uy;
+    __builtin_memcpy(&ux, &x, 2);
+    __builtin_memcpy(&uy, &y, 2);
+    return (uint32_t)ux | ((uint32_t)uy << 16);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hbits) { return __uint_as_float(hbits << 16); }
+
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    constexpr int PAD = KS / 2;
+    const int S = P.stride;
+    const int THin = (P.TH - 1) * S + KS, TWin = (P.TW - 1) * S + KS;
+    const int PST = P.CK * 2 + 16;  // bytes per staged pixel (+16 B pad: spreads consecutive pixels over LDS banks)
+    const int cpk = P.CK >> 3;
+
+    int bidx = blockIdx.x;
+    const int tx_i = bidx % P.tiles_x;
+    bidx /= P.tiles_x;
+    const int ty_i = bidx % P.tiles_y;
+    const int b = bidx / P.tiles_y;
+    const int cb = blockIdx.y;
+    const int oy0 = ty_i * P.TH, ox0 = tx_i * P.TW;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+
+    // this lane's pixels (one per M fragment)
+    int pixbase[MF];
+    int opix[MF];  // output pixel linear index inside the image, or -1
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        int p = (wave * MF + mf) * 16 + pl;
+        int ty = (int)(((float)p + 0.5f) * P.inv_tw);
+        int tx = p - ty * P.TW;
+        bool ok = (p < P.TH * P.TW) && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout);
+        pixbase[mf] = ok ? ((ty * S) * TWin + tx * S) * PST : 0;
+        opix[mf] = ok ? ((oy0 + ty) * P.Wout + ox0 + tx) : -1;
+    }
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nq = (KS == 3 ? 9 : 1) * cpk;
+    const int in_px = THin * TWin;
+
+    for (int stage = 0; stage < P.nstage; ++stage) {
+        __syncthreads();
+        // ---- stage the input tile chunk [in_px][CK] into LDS
+        if constexpr (IN_U8) {
+            const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
+            for (int pix = tid; pix < in_px; pix += 256) {
+                int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
+                int ix = pix - iy * TWin;
+                int gy = iy0 + iy, gx = ix0 + ix;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
+                    const uint8_t *s = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
+                    uint32_t c0 = P.lut[s[P.flip_bgr ? 2 : 0]], c1 = P.lut[s[1]], c2 = P.lut[s[P.flip_bgr ? 0 : 2]];
+                    uint32_t c3 = (P.cin == 4) ? (uint32_t)P.lut[s[3]] : 0u;
+                    v.x = c0 | (c1 << 16);
+                    v.y = c2 | (c3 << 16);
+                }
+                *reinterpret_cast<uint4 *>(smem + pix * PST) = v;
+            }
+        } else {
+            const bf16_t *src = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co + stage * P.CK;
+            const int nchunk = in_px << P.sh;
+            const int crem = P.cin - stage * P.CK;  // channels left in this stage (multiple of 8)
+            for (int idx = tid; idx < nchunk; idx += 256) {
+                int pix = idx >> P.sh, c8 = idx & (cpk - 1);
+                int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
+                int ix = pix - iy * TWin;
+                int gy = iy0 + iy, gx = ix0 + ix;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win && c8 * 8 < crem)
+                    v = *reinterpret_cast<const uint4 *>(src + ((int64_t)gy * P.Win + gx) * P.in_cs + c8 * 8);
+                *reinterpret_cast<uint4 *>(smem + pix * PST + c8 * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- K loop over this stage: weights from global (fragment order), activations from LDS
+        const bf16x8 *wst = reinterpret_cast<const bf16x8 *>(P.wpk) + ((int64_t)(cb * P.nstage + stage) * P.kst) * NF * 64 + lane;
+        bf16x8 wcur[NF], wnxt[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wcur[f] = wst[f * 64];
+        for (int ks = 0; ks < P.kst; ++ks) {
+            if (ks + 1 < P.kst) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) wnxt[f] = wst[((ks + 1) * NF + f) * 64];
+            }
+            int q = ks * 4 + g;
+            q = q < nq ? q : nq - 1;  // padding k-steps: any valid address, their weights are zero
+            int off;
+            if constexpr (KS == 3) {
+                int tap = q >> P.sh, c0 = q & (cpk - 1);
+                int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+                off = (dy * TWin + dx) * PST + c0 * 16;
+            } else {
+                off = q * 16;
+            }
+            bf16x8 a[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const bf16x8 *>(smem + pixbase[mf] + off);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    acc[mf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[f], a[mf], acc[mf][f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) wcur[f] = wnxt[f];
+        }
+    }
+
+    // ---- epilogue: lane owns couts [cbase, cbase + 4*NF) of pixel opix[mf]
+    const int cbase = cb * 16 * NF + g * 4 * NF;
+    float bias[NF * 4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase + f * 4);
+        bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
+    }
+    const bool full = (cbase + 4 * NF <= P.cout);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        if (opix[mf] < 0) continue;
+        float v[NF * 4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[mf][f][r] + bias[f * 4 + r];
+                if (P.act) x = silu_f(x);
+                v[f * 4 + r] = x;
+            }
+        if (P.res) {
+            const bf16_t *rp = P.res + (int64_t)b * P.res_bs + (int64_t)opix[mf] * P.res_cs + P.res_co + cbase;
+            if (full) {
+#pragma unroll
+                for (int h = 0; h < NF / 2 + (NF == 1); ++h) {
+                    if constexpr (NF == 1) {
+                        uint2 rv = *reinterpret_cast<const uint2 *>(rp);
+                        v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                        v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                    } else {
+                        uint4 rv = *reinterpret_cast<const uint4 *>(rp + h * 8);
+                        v[h * 8 + 0] += bf16_bits_to_f32(rv.x & 0xffffu); v[h * 8 + 1] += bf16_bits_to_f32(rv.x >> 16);
+                        v[h * 8 + 2] += bf16_bits_to_f32(rv.y & 0xffffu); v[h * 8 + 3] += bf16_bits_to_f32(rv.y >> 16);
+                        v[h * 8 + 4] += bf16_bits_to_f32(rv.z & 0xffffu); v[h * 8 + 5] += bf16_bits_to_f32(rv.z >> 16);
+                        v[h * 8 + 6] += bf16_bits_to_f32(rv.w & 0xffffu); v[h * 8 + 7] += bf16_bits_to_f32(rv.w >> 16);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NF * 4; ++c)
+                    if (cbase + c < P.cout) v[c] += bf16_bits_to_f32(rp[c]);
+            }
+        }
+        if constexpr (OUT_F32) {
+            float *op = (float *)P.out + (int64_t)b * P.out_bs + (int64_t)opix[mf] * P.out_cs + P.out_co + cbase;
+#pragma unroll
+            for (int c = 0; c < NF * 4; ++c)
+                if (cbase + c < P.cout) op[c] = v[c];
+        } else {
+            bf16_t *op = (bf16_t *)P.out + (int64_t)b * P.out_bs + (int64_t)opix[mf] * P.out_cs + P.out_co + cbase;
+            if (full) {
+                if constexpr (NF == 1) {
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(op) = o;
+                } else {
+#pragma unroll
+                    for (int h = 0; h < NF / 2; ++h) {
+                        uint4 o;
+                        o.x = pack_bf16x2(v[h * 8 + 0], v[h * 8 + 1]); o.y = pack_bf16x2(v[h * 8 + 2], v[h * 8 + 3]);
+                        o.z = pack_bf16x2(v[h * 8 + 4], v[h * 8 + 5]); o.w = pack_bf16x2(v[h * 8 + 6], v[h * 8 + 7]);
+                        *reinterpret_cast<uint4 *>(op + h * 8) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NF * 4; ++c)
+                    if (cbase + c < P.cout) op[c] = (bf16_t)(pack_bf16x2(v[c], 0.f) & 0xffffu);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+int conv_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 8) + 3) / 4; }
+
+ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) {
+    ConvTiling t;
+    t.NF = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
+    if (ks == 1) {
+        // 1x1: the whole batch is one long pixel row (caller passes Hout = 1, Wout = B*H*W)
+        t.TH = 1; t.MF = 2; t.TW = 64 * t.MF;
+        t.CK = cin >= 64 ? 64 : 32;
+        return t;
+    }
+    int cin8 = (cin + 7) / 8 * 8;
+    if (Hout % 13 == 0 && Wout % 13 == 0) { t.TH = 13; t.TW = 13; t.MF = 3; }
+    else if (Hout >= 16 && Wout >= 16) { t.TH = 8; t.TW = 16; t.MF = 2; }
+    else { t.TH = 8; t.TW = 8; t.MF = 1; }
+    int ck = 1;
+    while (ck * 2 <= cin8 && ck * 2 <= 32) ck *= 2;  // power of two <= min(cin8, 32)
+    if (ck < 8) ck = 8;
+    if (stride == 2 && ck > 16) ck = 16;             // keep the (2T+1)^2 halo tile small enough for several groups per CU
+    t.CK = ck;
+    return t;
+}
+
+std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks, const ConvTiling &t, const int *perm, int in_u8) {
+    const int CK = t.CK, NF = t.NF, cpk = CK / 8;
+    const int cin_eff = in_u8 ? 8 : cin;
+    const int nstage = (cin_eff + CK - 1) / CK;
+    const int kst = conv_ksteps(ks, CK);
+    const int ncb = (cout + 16 * NF - 1) / (16 * NF);
+    const int taps = ks * ks;
+    std::vector<bf16_t> out((size_t)ncb * nstage * kst * NF * 64 * 8, 0);
+    size_t o = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int st = 0; st < nstage; ++st)
+            for (int k = 0; k < kst; ++k)
+                for (int f = 0; f < NF; ++f)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int r = lane & 15, gq = lane >> 4;
+                        int co = cb * 16 * NF + (r >> 2) * 4 * NF + f * 4 + (r & 3);
+                        int q = k * 4 + gq;
+                        int tap = (ks == 3) ? q / cpk : 0;
+                        int c0 = (ks == 3) ? (q % cpk) * 8 : q * 8;
+                        for (int j = 0; j < 8; ++j, ++o) {
+                            int c = st * CK + c0 + j;
+                            bool ok = co < cout && c < cin && tap < taps && (ks == 3 || c0 < CK);
+                            if (!ok) continue;
+                            int src = perm ? perm[co] : co;
+                            out[o] = f32_to_bf16(w[((size_t)src * cin + c) * taps + tap]);
+                        }
+                    }
+    return out;
+}
+
+size_t conv_lds_bytes(const ConvLaunch &L) {
+    int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
+    return (size_t)THin * TWin * (L.CK * 2 + 16);
+}
+
+template <int KS, int MF, int NF>
+static hipError_t launch_t(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.in_u8) {
+        if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false>), grid, dim3(256), lds, st, P);
+        else return hipErrorInvalidValue;
+    } else if (L.out_f32) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false>), grid, dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
+template <int KS, int MF>
+static hipError_t launch_nf(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    switch (L.NF) {
+        case 1: return launch_t<KS, MF, 1>(L, P, grid, lds, st);
+        case 2: return launch_t<KS, MF, 2>(L, P, grid, lds, st);
+        case 4: return launch_t<KS, MF, 4>(L, P, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
+    ConvParams P;
+    P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
+    P.out = L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
+    P.res = (const bf16_t *)L.res.p; P.res_bs = L.res.bs; P.res_cs = L.res.cs; P.res_co = L.res.co;
+    P.wpk = L.wpk; P.bias = L.bias; P.lut = L.lut;
+    P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout;
+    P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
+    P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2(L.CK / 8);
+    P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y;
+    int cin_eff = L.in_u8 ? 8 : L.cin;
+    P.nstage = (cin_eff + L.CK - 1) / L.CK;
+    P.kst = conv_ksteps(L.ks, L.CK);
+    int TWin = (L.TW - 1) * L.stride + L.ks;
+    P.inv_twin = 1.0f / (float)TWin;
+    P.inv_tw = 1.0f / (float)L.TW;
+    if ((1 << P.sh) != L.CK / 8 || L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
+    int ncb = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
+    dim3 grid((unsigned)((int64_t)L.B * L.tiles_y * L.tiles_x), (unsigned)ncb);
+    size_t lds = conv_lds_bytes(L);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (L.ks == 3) {
+        switch (L.MF) {
+            case 1: return launch_nf<3, 1>(L, P, grid, lds, st);
+            case 2: return launch_nf<3, 2>(L, P, grid, lds, st);
+            case 3: return launch_nf<3, 3>(L, P, grid, lds, st);
+        }
+    } else if (L.ks == 1) {
+        switch (L.MF) {
+            case 1: return launch_nf<1, 1>(L, P, grid, lds, st);
+            case 2: return launch_nf<1, 2>(L, P, grid, lds, st);
+            case 3: return launch_nf<1, 3>(L, P, grid, lds, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace obb

@@ -1,0 +1,546 @@
+// Model runtime: weight-blob loader, YOLO11-OBB graph builder (per input shape), buffer plan and forward executor.
+//
+// Replaces `YOLO("best416.pt")` + `model(net_input, ...)`'s OBBModel forward (Detect_OBB.py:26, 81-83; graph =
+// ultralytics==8.3.196 yolo11-obb.yaml).  The graph is lowered to a flat list of fused kernel
+// launches; Concat/chunk/split never materialise: every producer writes into the channel slice of the buffer its
+// consumer reads (TensorRef = base, batch stride, pixel stride, channel offset).
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+
+#include "ctx.h"
+#include "nnops.h"
+
+namespace obb {
+
+static constexpr int kRegMax = 16;
+
+struct ConvRecord {
+    std::string name;
+    int c1, c2, k, s, g, act;
+    const float *w, *b;  // into the retained host blob copy
+};
+
+struct Buf {
+    int H, W, C;
+    bool f32;
+    std::string name;
+    int64_t off = 0;  // byte offset into the slab per image-capacity unit (resolved at allocation)
+    void *p = nullptr;
+    int64_t per_img() const { return (int64_t)H * W * C; }
+};
+
+struct Slice { int buf = -1, co = 0, C = 0; };
+
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN };
+
+struct Op {
+    OpType type;
+    std::string name;
+    Slice in, out, res;
+    int H = 0, W = 0;        // input spatial dims
+    int Ho = 0, Wo = 0;      // output spatial dims
+    ConvLaunch conv;         // OP_CONV
+    bool one_d = false;
+    const float *dw_w = nullptr, *dw_b = nullptr;  // OP_DW (device)
+    int act = 0;
+    int N = 0, nh = 0, kd = 0, hd = 0;  // OP_ATTN
+    int head_level = -1;     // >= 0: output goes to the caller's head tensor at this level
+};
+
+struct Plan {
+    int h = 0, w = 0, A = 0, no = 0;
+    std::vector<Buf> bufs;
+    std::vector<Op> ops;
+    std::map<std::string, Slice> named;
+    std::vector<void *> dev_allocs;
+    int lvl_off[3] = {0, 0, 0};
+    int cap = 0;
+    void *slab = nullptr;
+    int64_t bytes_per_img = 0;
+    double macs_per_img = 0;
+    ~Plan() {
+        for (void *p : dev_allocs) (void)hipFree(p);
+        if (slab) (void)hipFree(slab);
+    }
+};
+
+struct Model {
+    std::vector<char> blob;
+    int nc = 0, ch = 0, max_ch = 0;
+    float width = 0, depth = 0;
+    std::string scale;
+    std::map<std::string, ConvRecord> recs;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
+    bf16_t *lut_dev = nullptr;
+    ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
+};
+
+// ---------------------------------------------------------------------------------------------- blob parsing ("OBBW" v1)
+#pragma pack(push, 1)
+struct BlobHeader { char magic[4]; uint32_t version, nrec; int32_t nc, ch; float width, depth; int32_t max_ch, reg_max; char scale[8]; };
+struct BlobRec { char name[64]; int32_t c1, c2, k, s, g, act; uint64_t w_off, b_off; };
+#pragma pack(pop)
+
+static int parse_blob(obb_ctx *ctx, Model &M) {
+    const size_t n = M.blob.size();
+    if (n < sizeof(BlobHeader)) return set_error(ctx, OBB_ERR_FORMAT, "weight blob too small (%zu bytes)", n);
+    BlobHeader H;
+    memcpy(&H, M.blob.data(), sizeof H);
+    if (memcmp(H.magic, "OBBW", 4) != 0 || H.version != 1) return set_error(ctx, OBB_ERR_FORMAT, "bad weight blob magic/version");
+    if (H.reg_max != kRegMax) return set_error(ctx, OBB_ERR_FORMAT, "reg_max %d unsupported", H.reg_max);
+    if (H.ch != 3 && H.ch != 4) return set_error(ctx, OBB_ERR_FORMAT, "input channels %d unsupported (3 or 4)", H.ch);
+    if (H.nc < 1 || H.nc > 1024) return set_error(ctx, OBB_ERR_FORMAT, "nc %d out of range", H.nc);
+    M.nc = H.nc; M.ch = H.ch; M.width = H.width; M.depth = H.depth; M.max_ch = H.max_ch;
+    M.scale = std::string(H.scale, strnlen(H.scale, 8));
+    size_t tbl = sizeof(BlobHeader);
+    if (tbl + (size_t)H.nrec * sizeof(BlobRec) > n) return set_error(ctx, OBB_ERR_FORMAT, "record table truncated");
+    for (uint32_t i = 0; i < H.nrec; ++i) {
+        BlobRec R;
+        memcpy(&R, M.blob.data() + tbl + i * sizeof(BlobRec), sizeof R);
+        ConvRecord c;
+        c.name = std::string(R.name, strnlen(R.name, 64));
+        c.c1 = R.c1; c.c2 = R.c2; c.k = R.k; c.s = R.s; c.g = R.g; c.act = R.act;
+        if (c.c1 <= 0 || c.c2 <= 0 || (c.k != 1 && c.k != 3) || c.g <= 0 || c.c1 % c.g)
+            return set_error(ctx, OBB_ERR_FORMAT, "record %s: unsupported conv shape", c.name.c_str());
+        size_t wn = (size_t)c.c2 * (c.c1 / c.g) * c.k * c.k * 4, bn = (size_t)c.c2 * 4;
+        if (R.w_off % 4 || R.b_off % 4 || R.w_off + wn > n || R.b_off + bn > n)
+            return set_error(ctx, OBB_ERR_FORMAT, "record %s: data out of range", c.name.c_str());
+        c.w = reinterpret_cast<const float *>(M.blob.data() + R.w_off);
+        c.b = reinterpret_cast<const float *>(M.blob.data() + R.b_off);
+        M.recs[c.name] = c;
+    }
+    return OBB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- graph builder
+static int make_divisible(double x, int d) { return (int)std::ceil(x / d) * d; }
+
+struct Builder {
+    obb_ctx *ctx;
+    Model &M;
+    Plan &P;
+    int err = OBB_OK;
+
+    int ch(int c) const { return make_divisible(std::min(c, M.max_ch) * (double)M.width, 8); }
+    int reps(int n) const { return n > 1 ? std::max((int)std::lround(n * (double)M.depth), 1) : n; }
+
+    int buf(int H, int W, int C, const std::string &name, bool f32 = false) {
+        Buf b;
+        b.H = H; b.W = W; b.C = C; b.f32 = f32; b.name = name;
+        P.bufs.push_back(b);
+        return (int)P.bufs.size() - 1;
+    }
+    Slice whole(int b) const { return Slice{b, 0, P.bufs[b].C}; }
+    Slice sub(int b, int co, int C) const { return Slice{b, co, C}; }
+
+    const ConvRecord *rec(const std::string &name) {
+        auto it = M.recs.find(name);
+        if (it == M.recs.end()) {
+            if (!err) err = set_error(ctx, OBB_ERR_FORMAT, "weight blob has no record '%s'", name.c_str());
+            return nullptr;
+        }
+        return &it->second;
+    }
+
+    template <typename T>
+    T *upload(const std::vector<T> &v) {
+        void *d = nullptr;
+        if (hipMalloc(&d, v.size() * sizeof(T) + 256) != hipSuccess) {
+            if (!err) err = set_error(ctx, OBB_ERR_HIP, "hipMalloc for weights failed");
+            return nullptr;
+        }
+        P.dev_allocs.push_back(d);
+        if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+            if (!err) err = set_error(ctx, OBB_ERR_HIP, "weight upload failed");
+            return nullptr;
+        }
+        return (T *)d;
+    }
+
+    // generic dense conv (groups == 1).  in.buf == -1 -> the uint8 network input.
+    void conv(const std::string &name, Slice in, int Hin, int Win, Slice out, Slice res = Slice(), int head_level = -1,
+              const int *perm = nullptr) {
+        const ConvRecord *r = rec(name);
+        if (!r || err) return;
+        bool in_u8 = in.buf < 0;
+        int cin = in_u8 ? M.ch : in.C;
+        if (r->g != 1 || r->c1 != cin || r->c2 != out.C) {
+            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: shape (%d->%d, g%d) does not match the graph (%d->%d)", name.c_str(), r->c1,
+                            r->c2, r->g, cin, out.C);
+            return;
+        }
+        Op op;
+        op.type = OP_CONV; op.name = name; op.in = in; op.out = out; op.res = res; op.head_level = head_level;
+        op.H = Hin; op.W = Win;
+        op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
+        op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
+        op.one_d = (r->k == 1 && head_level < 0);
+        ConvTiling t = plan_conv(op.one_d ? 1 : (r->k == 1 ? 3 /*2D tiling rules*/ : r->k), r->s, cin, r->c2, op.Ho, op.Wo);
+        if (r->k == 1 && !op.one_d) t.CK = cin >= 64 ? 64 : 32;
+        if (in_u8) t.CK = 8;
+        ConvLaunch &L = op.conv;
+        L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act;
+        L.in_u8 = in_u8; L.out_f32 = head_level >= 0; L.flip_bgr = (in_u8 && M.ch == 3);
+        L.TH = t.TH; L.TW = t.TW; L.MF = t.MF; L.NF = t.NF; L.CK = t.CK;
+        L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
+        L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
+        std::vector<bf16_t> pk = pack_conv_weights(r->w, r->c2, cin, r->k, t, perm, in_u8);
+        L.wpk = upload(pk);
+        std::vector<float> bias(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+        for (int c = 0; c < r->c2; ++c) bias[c] = r->b[perm ? perm[c] : c];
+        L.bias = upload(bias);
+        L.lut = M.lut_dev;
+        P.macs_per_img += (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+        P.ops.push_back(op);
+        P.named[name] = out;
+    }
+
+    void dwconv(const std::string &name, Slice in, int H, int W, Slice out, Slice res = Slice()) {
+        const ConvRecord *r = rec(name);
+        if (!r || err) return;
+        if (r->g != r->c1 || r->c1 != r->c2 || r->k != 3 || r->s != 1 || r->c1 != in.C || out.C != in.C) {
+            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: not a depthwise 3x3 matching the graph", name.c_str());
+            return;
+        }
+        int C = in.C;
+        std::vector<float> w((size_t)9 * C), b((size_t)C + 8, 0.f);
+        for (int c = 0; c < C; ++c) {
+            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = bf16_to_f32(f32_to_bf16(r->w[(size_t)c * 9 + t]));
+            b[c] = r->b[c];
+        }
+        Op op;
+        op.type = OP_DW; op.name = name; op.in = in; op.out = out; op.res = res; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+        op.act = r->act;
+        op.dw_w = upload(w);
+        op.dw_b = upload(b);
+        P.macs_per_img += (double)H * W * C * 9;
+        P.ops.push_back(op);
+        P.named[name] = out;
+    }
+
+    void pool(Slice in, int H, int W, Slice out) {
+        Op op; op.type = OP_POOL; op.name = "maxpool5"; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+        P.ops.push_back(op);
+    }
+    void upsample(Slice in, int H, int W, Slice out) {
+        Op op; op.type = OP_UP; op.name = "upsample2"; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = 2 * H; op.Wo = 2 * W;
+        P.ops.push_back(op);
+    }
+
+    void bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e) {
+        int c_ = (int)(out.C * e);
+        int t = buf(H, W, c_, name + ".t");
+        conv(name + ".cv1", in, H, W, whole(t));
+        conv(name + ".cv2", whole(t), H, W, out, in);  // shortcut add (c1 == c2)
+    }
+
+    void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
+        int c_ = out.C / 2;
+        int cat = buf(H, W, 2 * c_, name + ".cat");
+        int a = buf(H, W, c_, name + ".a");
+        conv(name + ".cv1", in, H, W, whole(a));
+        Slice cur = whole(a);
+        for (int i = 0; i < n; ++i) {
+            Slice dst = (i == n - 1) ? sub(cat, 0, c_) : whole(buf(H, W, c_, name + ".m" + std::to_string(i)));
+            bottleneck(name + ".m." + std::to_string(i), cur, H, W, dst, 1.0);
+            cur = dst;
+        }
+        conv(name + ".cv2", in, H, W, sub(cat, c_, c_));
+        conv(name + ".cv3", whole(cat), H, W, out);
+    }
+
+    void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e) {
+        std::string name = "model." + std::to_string(li);
+        int c = (int)(out.C * e);
+        int cat = buf(H, W, (2 + n) * c, name + ".cat");
+        conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
+        for (int i = 0; i < n; ++i) {
+            Slice src = sub(cat, (1 + i) * c, c), dst = sub(cat, (2 + i) * c, c);
+            if (use_c3k) c3k(name + ".m." + std::to_string(i), src, H, W, dst, 2);
+            else bottleneck(name + ".m." + std::to_string(i), src, H, W, dst, 0.5);
+        }
+        conv(name + ".cv2", whole(cat), H, W, out);
+    }
+
+    int build() {
+        const int h = P.h, w = P.w;
+        const bool big = M.scale == "m" || M.scale == "l" || M.scale == "x";
+        const int n2 = reps(2);
+        const int c64 = ch(64), c128 = ch(128), c256 = ch(256), c512 = ch(512), c1024 = ch(1024);
+        const int H2 = h / 2, W2 = w / 2, H4 = h / 4, W4 = w / 4, H8 = h / 8, W8 = w / 8, H16 = h / 16, W16 = w / 16, H32 = h / 32, W32 = w / 32;
+        // concat buffers that later layers read: producers write straight into their slices
+        int cat13 = buf(H16, W16, c1024 + c512, "cat13");  // [up(x10), x6]
+        int cat16 = buf(H8, W8, c512 + c512, "cat16");     // [up(x13), x4]
+        int cat19 = buf(H16, W16, c256 + c512, "cat19");   // [x17, x13]
+        int cat22 = buf(H32, W32, c512 + c1024, "cat22");  // [x20, x10]
+        Slice x4 = sub(cat16, c512, c512), x6 = sub(cat13, c1024, c512), x10 = sub(cat22, c512, c1024), x13 = sub(cat19, c256, c512);
+
+        int b0 = buf(H2, W2, c64, "x0");
+        conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
+        int b1 = buf(H4, W4, c128, "x1");
+        conv("model.1", whole(b0), H2, W2, whole(b1));
+        int b2 = buf(H4, W4, c256, "x2");
+        c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
+        int b3 = buf(H8, W8, c256, "x3");
+        conv("model.3", whole(b2), H4, W4, whole(b3));
+        c3k2(4, whole(b3), H8, W8, x4, n2, big, 0.25);
+        int b5 = buf(H16, W16, c512, "x5");
+        conv("model.5", x4, H8, W8, whole(b5));
+        c3k2(6, whole(b5), H16, W16, x6, n2, true, 0.5);
+        int b7 = buf(H32, W32, c1024, "x7");
+        conv("model.7", x6, H16, W16, whole(b7));
+        int b8 = buf(H32, W32, c1024, "x8");
+        c3k2(8, whole(b7), H32, W32, whole(b8), n2, true, 0.5);
+        // SPPF
+        int c_ = c1024 / 2;
+        int cat9 = buf(H32, W32, 4 * c_, "cat9");
+        conv("model.9.cv1", whole(b8), H32, W32, sub(cat9, 0, c_));
+        for (int i = 0; i < 3; ++i) pool(sub(cat9, i * c_, c_), H32, W32, sub(cat9, (i + 1) * c_, c_));
+        int b9 = buf(H32, W32, c1024, "x9");
+        conv("model.9.cv2", whole(cat9), H32, W32, whole(b9));
+        // C2PSA
+        int cp = c1024 / 2, nh = cp / 64, hd = cp / nh, kd = hd / 2;
+        int t10 = buf(H32, W32, 2 * cp, "psa.ab");
+        conv("model.10.cv1", whole(b9), H32, W32, whole(t10));
+        Slice bsl = sub(t10, cp, cp);
+        int qkvb = buf(H32, W32, cp + 2 * nh * kd, "psa.qkv"), ao = buf(H32, W32, cp, "psa.attn"), po = buf(H32, W32, cp, "psa.pe"),
+            ff = buf(H32, W32, 2 * cp, "psa.ffn");
+        // qkv output channels re-ordered [q_h0..q_h(nh-1) | k_h0.. | v_h0..] so that v is one contiguous slice
+        std::vector<int> perm(cp + 2 * nh * kd);
+        for (int hh = 0; hh < nh; ++hh) {
+            int src0 = hh * (2 * kd + hd);
+            for (int d = 0; d < kd; ++d) { perm[hh * kd + d] = src0 + d; perm[nh * kd + hh * kd + d] = src0 + kd + d; }
+            for (int d = 0; d < hd; ++d) perm[2 * nh * kd + hh * hd + d] = src0 + 2 * kd + d;
+        }
+        for (int i = 0; i < n2; ++i) {
+            std::string nm = "model.10.m." + std::to_string(i);
+            conv(nm + ".attn.qkv", bsl, H32, W32, whole(qkvb), Slice(), -1, perm.data());
+            Op at; at.type = OP_ATTN; at.name = nm + ".attn"; at.in = whole(qkvb); at.out = whole(ao); at.H = H32; at.W = W32; at.Ho = H32; at.Wo = W32;
+            at.N = H32 * W32; at.nh = nh; at.kd = kd; at.hd = hd;
+            P.macs_per_img += (double)nh * ((double)at.N * at.N * kd + (double)at.N * at.N * hd);
+            P.ops.push_back(at);
+            P.named[nm + ".attn"] = whole(ao);
+            dwconv(nm + ".attn.pe", sub(qkvb, 2 * nh * kd, cp), H32, W32, whole(po), whole(ao));
+            conv(nm + ".attn.proj", whole(po), H32, W32, bsl, bsl);  // x = x + attn(x), in place on the b half
+            conv(nm + ".ffn.0", bsl, H32, W32, whole(ff));
+            conv(nm + ".ffn.1", whole(ff), H32, W32, bsl, bsl);      // x = x + ffn(x)
+        }
+        conv("model.10.cv2", whole(t10), H32, W32, x10);
+        upsample(x10, H32, W32, sub(cat13, 0, c1024));
+        c3k2(13, whole(cat13), H16, W16, x13, n2, big, 0.5);
+        upsample(x13, H16, W16, sub(cat16, 0, c512));
+        int b16 = buf(H8, W8, c256, "x16");
+        c3k2(16, whole(cat16), H8, W8, whole(b16), n2, big, 0.5);
+        conv("model.17", whole(b16), H8, W8, sub(cat19, 0, c256));
+        int b19 = buf(H16, W16, c512, "x19");
+        c3k2(19, whole(cat19), H16, W16, whole(b19), n2, big, 0.5);
+        conv("model.20", whole(b19), H16, W16, sub(cat22, 0, c512));
+        int b22 = buf(H32, W32, c1024, "x22");
+        c3k2(22, whole(cat22), H32, W32, whole(b22), n2, true, 0.5);
+        // OBB head
+        const int chs[3] = {c256, c512, c1024};
+        const int feats[3] = {b16, b19, b22};
+        const int Hs[3] = {H8, H16, H32}, Ws[3] = {W8, W16, W32};
+        int c2 = std::max(std::max(16, chs[0] / 4), kRegMax * 4), c3 = std::max(chs[0], std::min(M.nc, 100)), c4 = std::max(chs[0] / 4, 1);
+        P.no = 4 * kRegMax + M.nc + 1;
+        int off = 0;
+        for (int i = 0; i < 3; ++i) { P.lvl_off[i] = off; off += Hs[i] * Ws[i]; }
+        P.A = off;
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "model.23.cv2." + std::to_string(i);
+            int t1 = buf(Hs[i], Ws[i], c2, p + ".t1"), t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
+            conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(t1));
+            conv(p + ".1", whole(t1), Hs[i], Ws[i], whole(t2));
+            conv(p + ".2", whole(t2), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i);
+        }
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "model.23.cv3." + std::to_string(i);
+            int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1"), e1 = buf(Hs[i], Ws[i], c3, p + ".e1"), d2 = buf(Hs[i], Ws[i], c3, p + ".d2"),
+                e2 = buf(Hs[i], Ws[i], c3, p + ".e2");
+            dwconv(p + ".0.0", whole(feats[i]), Hs[i], Ws[i], whole(d1));
+            conv(p + ".0.1", whole(d1), Hs[i], Ws[i], whole(e1));
+            dwconv(p + ".1.0", whole(e1), Hs[i], Ws[i], whole(d2));
+            conv(p + ".1.1", whole(d2), Hs[i], Ws[i], whole(e2));
+            conv(p + ".2", whole(e2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i);
+        }
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "model.23.cv4." + std::to_string(i);
+            int u1 = buf(Hs[i], Ws[i], c4, p + ".u1"), u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
+            conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
+            conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
+            conv(p + ".2", whole(u2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i);
+        }
+        for (const char *nm : {"x0", "x1", "x2", "x3", "x5", "x7", "x8", "x9", "x16", "x19", "x22"})
+            for (size_t b = 0; b < P.bufs.size(); ++b)
+                if (P.bufs[b].name == nm) P.named[nm] = whole((int)b);
+        P.named["x4"] = x4; P.named["x6"] = x6; P.named["x10"] = x10; P.named["x13"] = x13;
+        return err;
+    }
+};
+
+static int ensure_capacity(obb_ctx *ctx, Plan &P, int B) {
+    if (B <= P.cap) return OBB_OK;
+    int cap = std::max(B, 1);
+    int64_t off = 0;
+    for (Buf &b : P.bufs) {
+        b.off = off;
+        off += ((int64_t)cap * b.per_img() * (b.f32 ? 4 : 2) + 255) / 256 * 256;
+    }
+    void *slab = nullptr;
+    OBB_HIP(ctx, hipDeviceSynchronize());
+    if (P.slab) { (void)hipFree(P.slab); P.slab = nullptr; P.cap = 0; }
+    OBB_HIP(ctx, hipMalloc(&slab, (size_t)off + 256));
+    P.slab = slab;
+    P.cap = cap;
+    P.bytes_per_img = off / cap;
+    for (Buf &b : P.bufs) b.p = (char *)slab + b.off;
+    return OBB_OK;
+}
+
+static TensorRef tref(const Plan &P, const Slice &s) {
+    TensorRef t;
+    if (s.buf < 0) return t;
+    const Buf &b = P.bufs[s.buf];
+    t.p = b.p; t.bs = b.per_img(); t.cs = b.C; t.co = s.co;
+    return t;
+}
+
+static int get_plan(obb_ctx *ctx, int h, int w, Plan **out) {
+    if (!ctx->model) return set_error(ctx, OBB_ERR_STATE, "no model loaded (call obb_model_load first)");
+    OBB_REQUIRE(ctx, h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0 && h <= 1280 && w <= 1280,
+                "input %dx%d unsupported: both sides must be multiples of 32 in [32, 1280]", h, w);
+    Model &M = *ctx->model;
+    auto key = std::make_pair(h, w);
+    auto it = M.plans.find(key);
+    if (it == M.plans.end()) {
+        std::unique_ptr<Plan> P(new Plan());
+        P->h = h; P->w = w;
+        Builder B{ctx, M, *P};
+        int rc = B.build();
+        if (rc) return rc;
+        it = M.plans.emplace(key, std::move(P)).first;
+    }
+    *out = it->second.get();
+    return OBB_OK;
+}
+
+static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t st) {
+    Model &M = *ctx->model;
+    for (Op &op : P.ops) {
+        hipError_t e = hipSuccess;
+        switch (op.type) {
+            case OP_CONV: {
+                ConvLaunch L = op.conv;
+                L.B = B;
+                if (op.in.buf == -1) {
+                    L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
+                } else L.in = tref(P, op.in);
+                if (op.head_level >= 0) {
+                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no;
+                    L.out.bs = (int64_t)P.A * P.no; L.out.cs = P.no; L.out.co = op.out.co;
+                } else L.out = tref(P, op.out);
+                L.res = tref(P, op.res);
+                if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
+                    int64_t npx = (int64_t)B * op.Ho * op.Wo;
+                    L.B = 1; L.Hin = L.Hout = 1; L.Win = L.Wout = (int)npx;
+                    L.tiles_y = 1; L.tiles_x = (int)((npx + L.TW - 1) / L.TW);
+                }
+                e = launch_conv(L, st);
+                break;
+            }
+            case OP_DW: e = launch_dwconv3(tref(P, op.in), tref(P, op.out), tref(P, op.res), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, st); break;
+            case OP_POOL: e = launch_maxpool5(tref(P, op.in), tref(P, op.out), B, op.H, op.W, op.in.C, st); break;
+            case OP_UP: e = launch_upsample2(tref(P, op.in), tref(P, op.out), B, op.H, op.W, op.in.C, st); break;
+            case OP_ATTN: e = launch_attention(tref(P, op.in), tref(P, op.out), B, op.N, op.nh, op.kd, op.hd, st); break;
+        }
+        if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
+    }
+    return OBB_OK;
+}
+
+__global__ void k_bf16_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B,
+                                    float *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)B * npix_per_img * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t pix = (i / C) % npix_per_img;
+    int64_t b = i / ((int64_t)C * npix_per_img);
+    dst[i] = __uint_as_float((uint32_t)src[b * bs + pix * cs + co + c] << 16);
+}
+
+}  // namespace obb
+
+using namespace obb;
+
+extern "C" {
+
+int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
+    OBB_REQUIRE(ctx, ctx && blob_host && bytes > 0, "obb_model_load: bad arguments");
+    OBB_HIP(ctx, hipSetDevice(ctx->device));
+    OBB_HIP(ctx, hipDeviceSynchronize());
+    std::shared_ptr<Model> M(new Model());
+    M->blob.assign((const char *)blob_host, (const char *)blob_host + bytes);
+    int rc = parse_blob(ctx, *M);
+    if (rc) return rc;
+    // u8 -> bf16(v / 255): the predictor's `im.float() / 255` followed by the bf16 storage rounding, exactly
+    std::vector<bf16_t> lut(256);
+    for (int v = 0; v < 256; ++v) lut[v] = f32_to_bf16((float)v / 255.0f);
+    OBB_HIP(ctx, hipMalloc((void **)&M->lut_dev, 512));
+    OBB_HIP(ctx, hipMemcpy(M->lut_dev, lut.data(), 512, hipMemcpyHostToDevice));
+    ctx->model = M;
+    return OBB_OK;
+}
+
+int obb_model_info(const obb_ctx *cctx, int32_t h, int32_t w, int32_t *nc, int32_t *ch, int32_t *anchors, int32_t *nconv) {
+    obb_ctx *ctx = const_cast<obb_ctx *>(cctx);
+    OBB_REQUIRE(ctx, ctx, "obb_model_info: NULL context");
+    if (!ctx->model) return set_error(ctx, OBB_ERR_STATE, "no model loaded");
+    if (nc) *nc = ctx->model->nc;
+    if (ch) *ch = ctx->model->ch;
+    if (nconv) *nconv = (int32_t)ctx->model->recs.size();
+    if (anchors) {
+        OBB_REQUIRE(ctx, h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0, "obb_model_info: h, w must be multiples of 32");
+        *anchors = (h / 8) * (w / 8) + (h / 16) * (w / 16) + (h / 32) * (w / 32);
+    }
+    return OBB_OK;
+}
+
+int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0, "obb_forward: bad arguments");
+    if (B == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, tiles && head, "obb_forward: NULL buffer");
+    Plan *P = nullptr;
+    int rc = get_plan(ctx, h, w, &P);
+    if (rc) return rc;
+    rc = ensure_capacity(ctx, *P, B);
+    if (rc) return rc;
+    return run_forward(ctx, *P, tiles, B, head, (hipStream_t)s);
+}
+
+int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const char *name, float *out, int64_t max_elems,
+                         int64_t *n_elems, int32_t *shape_hwc_host, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && name && n_elems, "obb_debug_activation: bad arguments");
+    Plan *P = nullptr;
+    int rc = get_plan(ctx, h, w, &P);
+    if (rc) return rc;
+    auto it = P->named.find(name);
+    if (it == P->named.end() || it->second.buf < 0) return set_error(ctx, OBB_ERR_INVALID, "obb_debug_activation: no activation named '%s'", name);
+    OBB_REQUIRE(ctx, B <= P->cap, "obb_debug_activation: run obb_forward with B >= %d first", B);
+    const Slice &sl = it->second;
+    const Buf &b = P->bufs[sl.buf];
+    int64_t n = (int64_t)B * b.H * b.W * sl.C;
+    *n_elems = n;
+    if (shape_hwc_host) { shape_hwc_host[0] = b.H; shape_hwc_host[1] = b.W; shape_hwc_host[2] = sl.C; }
+    if (!out) return OBB_OK;
+    OBB_REQUIRE(ctx, max_elems >= n, "obb_debug_activation: output too small (%lld < %lld)", (long long)max_elems, (long long)n);
+    hipLaunchKernelGGL(k_bf16_slice_to_f32, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, b.per_img(), b.C,
+                       sl.co, sl.C, (int64_t)b.H * b.W, B, out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// The non-GEMM layers of the YOLO11-OBB forward: depthwise 3x3 (DWConv in the OBB head's
+// cls branch and the attention positional encoding), MaxPool2d(5,1,2) of SPPF, nearest x2 Upsample, and the
+// 2-head C2PSA attention.  All are HBM/LDS-bound VALU kernels on NHWC bf16 with 16 B (8-channel) accesses; each
+// writes straight into the channel slice of its consumer's concat buffer.
+#include "nnops.h"
+
+namespace obb {
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    uint16_t ux, uy;
+    __builtin_memcpy(&ux, &x, 2);
+    __builtin_memcpy(&uy, &y, 2);
+    return (uint32_t)ux | ((uint32_t)uy << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float *f) {
+    return make_uint4(pk2(f[0], f[1]), pk2(f[2], f[3]), pk2(f[4], f[5]), pk2(f[6], f[7]));
+}
+
+// ---------------------------------------------------------------- depthwise 3x3, stride 1, pad 1 (+bias, SiLU, +residual)
+// w: fp32 [9][C] (values already rounded to bf16), thread = (pixel, 8-channel chunk)
+__global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, TensorRef res, const float *__restrict__ w,
+                                                const float *__restrict__ bias, int B, int H, int W, int C, int act) {
+    const int c8n = C >> 3;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)B * H * W * c8n;
+    if (idx >= total) return;
+    int c8 = (int)(idx % c8n);
+    int64_t pix = idx / c8n;
+    int x = (int)(pix % W);
+    int y = (int)((pix / W) % H);
+    int b = (int)(pix / ((int64_t)W * H));
+    const bf16_t *ip = (const bf16_t *)in.p + (int64_t)b * in.bs + in.co + c8 * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        int yy = y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int xx = x + kx - 1;
+            if (xx < 0 || xx >= W) continue;
+            uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yy * W + xx) * in.cs);
+            float f[8];
+            unpack8(v, f);
+            const float4 *wp = reinterpret_cast<const float4 *>(w + (ky * 3 + kx) * C + c8 * 8);
+            float4 w0 = wp[0], w1 = wp[1];
+            acc[0] += f[0] * w0.x; acc[1] += f[1] * w0.y; acc[2] += f[2] * w0.z; acc[3] += f[3] * w0.w;
+            acc[4] += f[4] * w1.x; acc[5] += f[5] * w1.y; acc[6] += f[6] * w1.z; acc[7] += f[7] * w1.w;
+        }
+    }
+    const float4 *bp = reinterpret_cast<const float4 *>(bias + c8 * 8);
+    float4 b0 = bp[0], b1 = bp[1];
+    float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j] + bb[j];
+        if (act) v = v / (1.0f + __expf(-v));
+        acc[j] = v;
+    }
+    int64_t opix = (int64_t)y * W + x;
+    if (res.p) {
+        uint4 rv = *reinterpret_cast<const uint4 *>((const bf16_t *)res.p + (int64_t)b * res.bs + opix * res.cs + res.co + c8 * 8);
+        float rf[8];
+        unpack8(rv, rf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += rf[j];
+    }
+    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + opix * out.cs + out.co + c8 * 8) = pack8(acc);
+}
+
+// ---------------------------------------------------------------- MaxPool2d(k=5, s=1, p=2)  (implicit -inf padding)
+__global__ __launch_bounds__(256) void k_maxpool5(TensorRef in, TensorRef out, int B, int H, int W, int C) {
+    const int c8n = C >> 3;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)B * H * W * c8n;
+    if (idx >= total) return;
+    int c8 = (int)(idx % c8n);
+    int64_t pix = idx / c8n;
+    int x = (int)(pix % W);
+    int y = (int)((pix / W) % H);
+    int b = (int)(pix / ((int64_t)W * H));
+    const bf16_t *ip = (const bf16_t *)in.p + (int64_t)b * in.bs + in.co + c8 * 8;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int yy = max(0, y - 2); yy <= min(H - 1, y + 2); ++yy)
+        for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) {
+            uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yy * W + xx) * in.cs);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+        }
+    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + ((int64_t)y * W + x) * out.cs + out.co + c8 * 8) = pack8(m);
+}
+
+// ---------------------------------------------------------------- nearest-neighbour x2 upsample (pure copy)
+__global__ __launch_bounds__(256) void k_upsample2(TensorRef in, TensorRef out, int B, int H, int W, int C) {
+    const int c8n = C >> 3;
+    const int Ho = H * 2, Wo = W * 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)B * Ho * Wo * c8n;
+    if (idx >= total) return;
+    int c8 = (int)(idx % c8n);
+    int64_t pix = idx / c8n;
+    int x = (int)(pix % Wo);
+    int y = (int)((pix / Wo) % Ho);
+    int b = (int)(pix / ((int64_t)Wo * Ho));
+    uint4 v = *reinterpret_cast<const uint4 *>((const bf16_t *)in.p + (int64_t)b * in.bs + ((int64_t)(y >> 1) * W + (x >> 1)) * in.cs + in.co + c8 * 8);
+    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + ((int64_t)y * Wo + x) * out.cs + out.co + c8 * 8) = v;
+}
+
+// ---------------------------------------------------------------- C2PSA attention core
+// qkv slice layout per token (channels permuted by the weight loader): [q: nh*KD][k: nh*KD][v: nh*HD].
+// One workgroup per (tile, head): K and V of all N tokens live in LDS as fp32; a thread owns query rows.
+// out[n, h*HD + d] = sum_m softmax_m(q_n . k_m * scale) * v_m[d]   (two-pass softmax in fp32, like torch.softmax)
+template <int KD, int HD>
+__global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out, int N, int nh, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *sk = sm;                      // [N][KD+1]
+    float *sv = sm + (size_t)N * (KD + 1);  // [N][HD]
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const bf16_t *base = (const bf16_t *)qkv.p + (int64_t)b * qkv.bs + qkv.co;
+    for (int i = threadIdx.x; i < N * (KD / 8); i += 256) {
+        int n = i / (KD / 8), c = i % (KD / 8);
+        uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + nh * KD + h * KD + c * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sk[n * (KD + 1) + c * 8 + j] = f[j];
+    }
+    for (int i = threadIdx.x; i < N * (HD / 8); i += 256) {
+        int n = i / (HD / 8), c = i % (HD / 8);
+        uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + 2 * nh * KD + h * HD + c * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[n * HD + c * 8 + j] = f[j];
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float q[KD];
+#pragma unroll
+        for (int c = 0; c < KD / 8; ++c) {
+            uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + h * KD + c * 8);
+            unpack8(v, &q[c * 8]);
+        }
+        float mx = -INFINITY;
+        for (int m = 0; m < N; ++m) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < KD; ++d) s += q[d] * sk[m * (KD + 1) + d];
+            mx = fmaxf(mx, s * scale);
+        }
+        float acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        float den = 0.f;
+        for (int m = 0; m < N; ++m) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < KD; ++d) s += q[d] * sk[m * (KD + 1) + d];
+            float p = __expf(s * scale - mx);
+            den += p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] += p * sv[m * HD + d];
+        }
+        float inv = 1.0f / den;
+        bf16_t *op = (bf16_t *)out.p + (int64_t)b * out.bs + (int64_t)n * out.cs + out.co + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = acc[c * 8 + j] * inv;
+            *reinterpret_cast<uint4 *>(op + c * 8) = pack8(f);
+        }
+    }
+}
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B,
+                          int H, int W, int C, int act, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dwconv3, dim3(blocks_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_maxpool5, dim3(blocks_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, st, in, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample2(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_upsample2, dim3(blocks_for((int64_t)B * H * W * 4 * (C / 8))), dim3(256), 0, st, in, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, hipStream_t st) {
+    if (kd != 32 || hd != 64) return hipErrorInvalidValue;  // head_dim is 64 for every YOLO11 scale (heads = c/64)
+    size_t lds = sizeof(float) * ((size_t)N * (32 + 1) + (size_t)N * 64);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;  // N <= 422 tokens (input up to 640x640)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_attention<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    float scale = (float)(1.0 / sqrt((double)kd));  // python: key_dim ** -0.5 evaluated in double, applied to an fp32 tensor
+    hipLaunchKernelGGL((k_attention<32, 64>), dim3((unsigned)(B * nh)), dim3(256), lds, st, qkv, out, N, nh, scale);
+    return hipGetLastError();
+}
+
+}  // namespace obb

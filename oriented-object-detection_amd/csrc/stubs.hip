@@ -6,10 +6,6 @@ using namespace obb;
 extern "C" {
 int obb_gather_tiles(obb_ctx *ctx, const uint8_t *, int32_t, int32_t, int32_t, const int32_t *, int32_t, int32_t, uint8_t *, obb_stream_t) { NOT_YET(ctx, "obb_gather_tiles"); }
 int obb_letterbox(obb_ctx *ctx, const uint8_t *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, uint8_t *, int32_t, int32_t, obb_stream_t) { NOT_YET(ctx, "obb_letterbox"); }
-int obb_model_load(obb_ctx *ctx, const void *, size_t) { NOT_YET(ctx, "obb_model_load"); }
-int obb_model_info(const obb_ctx *ctx, int32_t, int32_t, int32_t *, int32_t *, int32_t *, int32_t *) { NOT_YET((obb_ctx *)ctx, "obb_model_info"); }
-int obb_forward(obb_ctx *ctx, const uint8_t *, int32_t, int32_t, int32_t, float *, obb_stream_t) { NOT_YET(ctx, "obb_forward"); }
-int obb_debug_activation(obb_ctx *ctx, int32_t, int32_t, int32_t, int32_t, float *, int64_t, int64_t *, int32_t *, obb_stream_t) { NOT_YET(ctx, "obb_debug_activation"); }
 int obb_decode_nms(obb_ctx *ctx, const float *, int32_t, int32_t, int32_t, float, float, int32_t, float *, int32_t *, obb_stream_t) { NOT_YET(ctx, "obb_decode_nms"); }
 int obb_decode(obb_ctx *ctx, const float *, int32_t, int32_t, int32_t, float *, obb_stream_t) { NOT_YET(ctx, "obb_decode"); }
 int obb_probiou_nms(obb_ctx *ctx, const float *, const float *, int64_t, float, int32_t *, uint8_t *, obb_stream_t) { NOT_YET(ctx, "obb_probiou_nms"); }

@@ -162,3 +162,41 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
     _call("obb_tile_postprocess", ctx(lp.device), _p(lp), _p(c), _p(dt), n, _p(r), r.shape[0], int(margin), int(strike_cls),
           _p(gb), _p(ang), _p(ins), _stream())
     return gb, ang, ins
+
+
+# ---------------------------------------------------------------- S1 model
+
+def model_load(blob, device=None):
+    """blob: bytes of an "OBBW" weight blob (host).  One model per context."""
+    c = ctx(device)
+    buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+    _call("obb_model_load", c, buf, len(blob))
+
+
+def model_info(h, w, device=None):
+    c = ctx(device)
+    nc, ch, a, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _call("obb_model_info", c, h, w, C.byref(nc), C.byref(ch), C.byref(a), C.byref(n))
+    return {"nc": nc.value, "ch": ch.value, "anchors": a.value, "nconv": n.value}
+
+
+def forward(tiles):
+    """tiles uint8 [B,h,w,ch] NHWC (BGR for 3-channel input, as the reference passes crops) -> raw head [B,A,64+nc+1] f32."""
+    t = _chk(tiles, torch.uint8, "tiles")
+    B, h, w, ch = t.shape
+    info = model_info(h, w, t.device)
+    if ch != info["ch"]:
+        raise ValueError(f"forward: model expects {info['ch']} input channels, got {ch}")
+    head = torch.empty((B, info["anchors"], 64 + info["nc"] + 1), dtype=torch.float32, device=t.device)
+    _call("obb_forward", ctx(t.device), _p(t), B, h, w, _p(head), _stream())
+    return head
+
+
+def debug_activation(name, B, h, w, device=None):
+    c = ctx(device)
+    n = C.c_int64(0)
+    shp = (C.c_int32 * 3)()
+    _call("obb_debug_activation", c, h, w, B, name.encode(), None, 0, C.byref(n), shp, _stream())
+    out = torch.empty((B, shp[0], shp[1], shp[2]), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    _call("obb_debug_activation", c, h, w, B, name.encode(), _p(out), out.numel(), C.byref(n), shp, _stream())
+    return out

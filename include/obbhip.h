@@ -42,6 +42,11 @@ int obb_ctx_destroy(obb_ctx *ctx);
 /* Last error text of this context (or of the calling thread when ctx == NULL). */
 const char *obb_last_error(const obb_ctx *ctx);
 
+/* Engine knobs (no reference counterpart).  "precision": 16 = fp16 activation/weight storage (default; what
+ * Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32 accumulation either way.  Applies to the next
+ * obb_model_load. */
+int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
+
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */
 /* out[i] = IoU(a[i], b[i]); a, b: double[m*8].  Replaces Shapely Polygon/is_valid/intersection/area per pair. */
 int obb_poly_iou_pairs(obb_ctx *ctx, const double *a, const double *b, int64_t m, double *out, obb_stream_t s);

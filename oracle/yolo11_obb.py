@@ -6,10 +6,11 @@ ultralytics is NOT under /root/reference and not installable here, so this resta
 Appendix A3.  Pinned by the published parameter table (n: 2.66 M params with nc=80) in tests/test_oracle_model.py;
 otherwise **parity unpinned** (no real checkpoint or Ultralytics install is available offline).
 
-Two precisions:
-  * "fp32" -- what the reference computes on CPU (half=False).
-  * "bf16" -- same graph with the HIP path's rounding points (bf16 storage of every activation tensor, bf16 weights,
-              fp32 accumulate/bias/SiLU/residual) so that kernel bugs are not hidden behind a loose tolerance.
+Precisions:
+  * "fp32"          -- what the reference computes on CPU (half=False).
+  * "f16" / "bf16"  -- same graph with the HIP path's rounding points (16-bit storage of every activation tensor and
+                       of the weights, fp32 accumulate/bias/SiLU/residual) so that kernel bugs are not hidden behind
+                       a loose tolerance.
 
 Weights are synthetic (no checkpoint exists offline): seeded, variance-preserving, BN already folded.
 """
@@ -36,6 +37,11 @@ def make_divisible(x, d=8):
 
 def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+def half_round(t, mode):
+    """round-to-nearest-even to the 16-bit storage type of the HIP path ("f16" or "bf16")"""
+    return t.to(torch.float16 if mode == "f16" else torch.bfloat16).to(torch.float32)
 
 
 class ConvRec:
@@ -213,7 +219,7 @@ class Yolo11OBB:
 
     # ------------------------------------------------------------------ forward
     def _q(self, t):
-        return bf16_round(t) if self.bf16 else t
+        return half_round(t, self.mode) if self.bf16 else t
 
     def _apply_conv(self, name, x, residual=None, out_f32=False):
         r = self.convs[name]
@@ -224,15 +230,16 @@ class Yolo11OBB:
             final = name.startswith("model.23.") and name.endswith(".2")
             r.w = (r.w / sd.view(-1, 1, 1, 1)).contiguous()
             r.b = r.b - mu / sd if not final else r.b - mu / sd
-        w = bf16_round(r.w) if self.bf16 else r.w
+        w = half_round(r.w, self.mode) if self.bf16 else r.w
         y = F.conv2d(x, w, r.b, stride=r.s, padding=r.k // 2, groups=r.g)
         if r.act:
             y = y / (1.0 + torch.exp(-y))  # SiLU
         if residual is not None:
             y = residual + y
+        y = y if out_f32 else self._q(y)
         if self.taps is not None:
             self.taps[name] = y
-        return y if out_f32 else self._q(y)
+        return y
 
     def _bneck(self, name, x):
         return self._apply_conv(name + ".cv2", self._apply_conv(name + ".cv1", x), residual=x)
@@ -276,7 +283,8 @@ class Yolo11OBB:
     def forward_raw(self, tiles_u8_nhwc, precision="fp32", taps=None):
         """tiles uint8 [B,H,W,ch] (BGR for ch==3, exactly what the reference hands to model(...)).
         -> raw head [B, A, 64+nc+1] fp32: per anchor 4x16 DFL logits, nc class logits, 1 angle logit."""
-        self.bf16 = precision == "bf16"
+        self.mode = precision
+        self.bf16 = precision in ("bf16", "f16")  # 16-bit storage emulation on
         self.taps = taps
         self.calib = getattr(self, "calib", False)
         x = torch.as_tensor(np.ascontiguousarray(tiles_u8_nhwc))

@@ -17,6 +17,7 @@ SIGNATURES = {
     "obb_ctx_create": [C.c_int, C.POINTER(_V)],
     "obb_ctx_destroy": [_V],
     "obb_last_error": [_V],
+    "obb_set_option": [_V, C.c_char_p, C.c_int64],
     "obb_poly_iou_pairs": [_V, _V, _V, C.c_int64, _V, _V],
     "obb_poly_iou_matrix": [_V, _V, _V, C.c_int64, _V, _V, C.c_int64, _V, _V],
     "obb_sort_desc_stable": [_V, _V, C.c_int64, _V, _V],

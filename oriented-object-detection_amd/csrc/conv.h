@@ -5,9 +5,11 @@
 #include <cstdint>
 #include <vector>
 
+#include "halfx.h"
+
 namespace obb {
 
-typedef uint16_t bf16_t;  // raw bits
+typedef half_bits_t bf16_t;  // raw 16-bit storage (fp16 or bf16, see halfx.h)
 
 // One fused conv launch: out[b, oy, ox, co] = epilogue( sum_{ky,kx,ci} in[b, oy*s+ky-p, ox*s+kx-p, ci] * W[co][ci][ky][kx] )
 // epilogue: + bias -> SiLU (optional) -> + residual (optional) -> bf16 (or fp32) store into a channel slice of `out`.
@@ -30,6 +32,7 @@ struct ConvLaunch {
     int ks = 1, stride = 1;
     int act = 1;
     int in_u8 = 0, out_f32 = 0, flip_bgr = 0;
+    int f16 = 1;  // storage type: 1 = fp16, 0 = bf16
     // tiling (chosen by plan_conv)
     int TH = 1, TW = 64, MF = 1, NF = 4, CK = 32;
     int tiles_y = 1, tiles_x = 1;
@@ -44,23 +47,10 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout);
 //   [cout_block][stage][kstep][nf][lane 0..63][8]
 // with the cout permutation that makes every lane own 4*NF contiguous output channels (see conv.hip).
 std::vector<bf16_t> pack_conv_weights(const float *w_oihw, int cout, int cin, int ks, const ConvTiling &t,
-                                      const int *cout_perm /* optional: logical cout -> source row */, int in_u8);
+                                      const int *cout_perm /* optional: logical cout -> source row */, int in_u8, bool f16);
 
 int conv_ksteps(int ks, int CK);
 size_t conv_lds_bytes(const ConvLaunch &L);
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st);
-
-inline bf16_t f32_to_bf16(float f) {
-    uint32_t u;
-    __builtin_memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-inline float bf16_to_f32(bf16_t h) {
-    uint32_t u = (uint32_t)h << 16;
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
-}
 
 }  // namespace obb

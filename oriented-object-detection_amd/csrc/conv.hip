@@ -23,7 +23,6 @@
 
 namespace obb {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct ConvParams {
@@ -38,19 +37,9 @@ struct ConvParams {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    // round-to-nearest-even via the hardware convert (keeps NaN a NaN)
-    __bf16 x = (__bf16)a, y = (__bf16)b;
-    uint16_t ux, uy;
-    __builtin_memcpy(&ux, &x, 2);
-    __builtin_memcpy(&uy, &y, 2);
-    return (uint32_t)ux | ((uint32_t)uy << 16);
-}
-
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hbits) { return __uint_as_float(hbits << 16); }
-
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32>
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16>
 __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
+    typedef typename HX<F16>::vec8 bf16x8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
@@ -154,7 +143,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
-                    acc[mf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[f], a[mf], acc[mf][f], 0, 0, 0);
+                    acc[mf][f] = HX<F16>::mfma(wcur[f], a[mf], acc[mf][f]);
 #pragma unroll
             for (int f = 0; f < NF; ++f) wcur[f] = wnxt[f];
         }
@@ -188,20 +177,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
                 for (int h = 0; h < NF / 2 + (NF == 1); ++h) {
                     if constexpr (NF == 1) {
                         uint2 rv = *reinterpret_cast<const uint2 *>(rp);
-                        v[0] += bf16_bits_to_f32(rv.x & 0xffffu); v[1] += bf16_bits_to_f32(rv.x >> 16);
-                        v[2] += bf16_bits_to_f32(rv.y & 0xffffu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                        v[0] += HX<F16>::lo(rv.x); v[1] += HX<F16>::hi(rv.x);
+                        v[2] += HX<F16>::lo(rv.y); v[3] += HX<F16>::hi(rv.y);
                     } else {
                         uint4 rv = *reinterpret_cast<const uint4 *>(rp + h * 8);
-                        v[h * 8 + 0] += bf16_bits_to_f32(rv.x & 0xffffu); v[h * 8 + 1] += bf16_bits_to_f32(rv.x >> 16);
-                        v[h * 8 + 2] += bf16_bits_to_f32(rv.y & 0xffffu); v[h * 8 + 3] += bf16_bits_to_f32(rv.y >> 16);
-                        v[h * 8 + 4] += bf16_bits_to_f32(rv.z & 0xffffu); v[h * 8 + 5] += bf16_bits_to_f32(rv.z >> 16);
-                        v[h * 8 + 6] += bf16_bits_to_f32(rv.w & 0xffffu); v[h * 8 + 7] += bf16_bits_to_f32(rv.w >> 16);
+                        v[h * 8 + 0] += HX<F16>::lo(rv.x); v[h * 8 + 1] += HX<F16>::hi(rv.x);
+                        v[h * 8 + 2] += HX<F16>::lo(rv.y); v[h * 8 + 3] += HX<F16>::hi(rv.y);
+                        v[h * 8 + 4] += HX<F16>::lo(rv.z); v[h * 8 + 5] += HX<F16>::hi(rv.z);
+                        v[h * 8 + 6] += HX<F16>::lo(rv.w); v[h * 8 + 7] += HX<F16>::hi(rv.w);
                     }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < NF * 4; ++c)
-                    if (cbase + c < P.cout) v[c] += bf16_bits_to_f32(rp[c]);
+                    if (cbase + c < P.cout) v[c] += HX<F16>::one(rp[c]);
             }
         }
         if constexpr (OUT_F32) {
@@ -214,21 +203,21 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
             if (full) {
                 if constexpr (NF == 1) {
                     uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(op) = o;
                 } else {
 #pragma unroll
                     for (int h = 0; h < NF / 2; ++h) {
                         uint4 o;
-                        o.x = pack_bf16x2(v[h * 8 + 0], v[h * 8 + 1]); o.y = pack_bf16x2(v[h * 8 + 2], v[h * 8 + 3]);
-                        o.z = pack_bf16x2(v[h * 8 + 4], v[h * 8 + 5]); o.w = pack_bf16x2(v[h * 8 + 6], v[h * 8 + 7]);
+                        o.x = HX<F16>::pack2(v[h * 8 + 0], v[h * 8 + 1]); o.y = HX<F16>::pack2(v[h * 8 + 2], v[h * 8 + 3]);
+                        o.z = HX<F16>::pack2(v[h * 8 + 4], v[h * 8 + 5]); o.w = HX<F16>::pack2(v[h * 8 + 6], v[h * 8 + 7]);
                         *reinterpret_cast<uint4 *>(op + h * 8) = o;
                     }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < NF * 4; ++c)
-                    if (cbase + c < P.cout) op[c] = (bf16_t)(pack_bf16x2(v[c], 0.f) & 0xffffu);
+                    if (cbase + c < P.cout) op[c] = (bf16_t)(HX<F16>::pack2(v[c], 0.f) & 0xffffu);
             }
         }
     }
@@ -261,7 +250,7 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) 
     return t;
 }
 
-std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks, const ConvTiling &t, const int *perm, int in_u8) {
+std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks, const ConvTiling &t, const int *perm, int in_u8, bool f16) {
     const int CK = t.CK, NF = t.NF, cpk = CK / 8;
     const int cin_eff = in_u8 ? 8 : cin;
     const int nstage = (cin_eff + CK - 1) / CK;
@@ -285,7 +274,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
                             bool ok = co < cout && c < cin && tap < taps && (ks == 3 || c0 < CK);
                             if (!ok) continue;
                             int src = perm ? perm[co] : co;
-                            out[o] = f32_to_bf16(w[((size_t)src * cin + c) * taps + tap]);
+                            out[o] = host_to_half(w[((size_t)src * cin + c) * taps + tap], f16);
                         }
                     }
     return out;
@@ -296,14 +285,19 @@ size_t conv_lds_bytes(const ConvLaunch &L) {
     return (size_t)THin * TWin * (L.CK * 2 + 16);
 }
 
+template <int KS, int MF, int NF, bool F16>
+static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.in_u8) {
+        if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false, F16>), grid, dim3(256), lds, st, P);
+        else return hipErrorInvalidValue;
+    } else if (L.out_f32) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, true, F16>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16>), grid, dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
 template <int KS, int MF, int NF>
 static hipError_t launch_t(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    if (L.in_u8) {
-        if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false>), grid, dim3(256), lds, st, P);
-        else return hipErrorInvalidValue;
-    } else if (L.out_f32) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, true>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false>), grid, dim3(256), lds, st, P);
-    return hipGetLastError();
+    return L.f16 ? launch_t2<KS, MF, NF, true>(L, P, grid, lds, st) : launch_t2<KS, MF, NF, false>(L, P, grid, lds, st);
 }
 
 template <int KS, int MF>

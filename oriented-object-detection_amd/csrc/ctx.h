@@ -23,6 +23,7 @@ struct obb_ctx {
     struct Slot { void *p = nullptr; size_t bytes = 0; };
     std::vector<Slot> ws;
     std::shared_ptr<obb::Model> model;
+    bool opt_f16 = true;
     void *workspace(int slot, size_t bytes);
     ~obb_ctx();
 };

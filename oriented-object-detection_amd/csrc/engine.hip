@@ -75,6 +75,7 @@ struct Model {
     std::map<std::string, ConvRecord> recs;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     bf16_t *lut_dev = nullptr;
+    bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
 };
 
@@ -183,11 +184,11 @@ struct Builder {
         if (in_u8) t.CK = 8;
         ConvLaunch &L = op.conv;
         L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act;
-        L.in_u8 = in_u8; L.out_f32 = head_level >= 0; L.flip_bgr = (in_u8 && M.ch == 3);
+        L.in_u8 = in_u8; L.out_f32 = head_level >= 0; L.flip_bgr = (in_u8 && M.ch == 3); L.f16 = M.f16;
         L.TH = t.TH; L.TW = t.TW; L.MF = t.MF; L.NF = t.NF; L.CK = t.CK;
         L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
         L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
-        std::vector<bf16_t> pk = pack_conv_weights(r->w, r->c2, cin, r->k, t, perm, in_u8);
+        std::vector<bf16_t> pk = pack_conv_weights(r->w, r->c2, cin, r->k, t, perm, in_u8, M.f16);
         L.wpk = upload(pk);
         std::vector<float> bias(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
         for (int c = 0; c < r->c2; ++c) bias[c] = r->b[perm ? perm[c] : c];
@@ -208,7 +209,7 @@ struct Builder {
         int C = in.C;
         std::vector<float> w((size_t)9 * C), b((size_t)C + 8, 0.f);
         for (int c = 0; c < C; ++c) {
-            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = bf16_to_f32(f32_to_bf16(r->w[(size_t)c * 9 + t]));
+            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = host_from_half(host_to_half(r->w[(size_t)c * 9 + t], M.f16), M.f16);
             b[c] = r->b[c];
         }
         Op op;
@@ -451,17 +452,18 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_conv(L, st);
                 break;
             }
-            case OP_DW: e = launch_dwconv3(tref(P, op.in), tref(P, op.out), tref(P, op.res), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, st); break;
-            case OP_POOL: e = launch_maxpool5(tref(P, op.in), tref(P, op.out), B, op.H, op.W, op.in.C, st); break;
+            case OP_DW: e = launch_dwconv3(tref(P, op.in), tref(P, op.out), tref(P, op.res), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
+            case OP_POOL: e = launch_maxpool5(tref(P, op.in), tref(P, op.out), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_UP: e = launch_upsample2(tref(P, op.in), tref(P, op.out), B, op.H, op.W, op.in.C, st); break;
-            case OP_ATTN: e = launch_attention(tref(P, op.in), tref(P, op.out), B, op.N, op.nh, op.kd, op.hd, st); break;
+            case OP_ATTN: e = launch_attention(tref(P, op.in), tref(P, op.out), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
     }
     return OBB_OK;
 }
 
-__global__ void k_bf16_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B,
+template <bool F16>
+__global__ void k_half_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B,
                                     float *__restrict__ dst) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)B * npix_per_img * C;
@@ -469,7 +471,7 @@ __global__ void k_bf16_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, 
     int c = (int)(i % C);
     int64_t pix = (i / C) % npix_per_img;
     int64_t b = i / ((int64_t)C * npix_per_img);
-    dst[i] = __uint_as_float((uint32_t)src[b * bs + pix * cs + co + c] << 16);
+    dst[i] = HX<F16>::one(src[b * bs + pix * cs + co + c]);
 }
 
 }  // namespace obb
@@ -486,13 +488,25 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     M->blob.assign((const char *)blob_host, (const char *)blob_host + bytes);
     int rc = parse_blob(ctx, *M);
     if (rc) return rc;
-    // u8 -> bf16(v / 255): the predictor's `im.float() / 255` followed by the bf16 storage rounding, exactly
+    M->f16 = ctx->opt_f16;
+    // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
-    for (int v = 0; v < 256; ++v) lut[v] = f32_to_bf16((float)v / 255.0f);
+    for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
     OBB_HIP(ctx, hipMalloc((void **)&M->lut_dev, 512));
     OBB_HIP(ctx, hipMemcpy(M->lut_dev, lut.data(), 512, hipMemcpyHostToDevice));
     ctx->model = M;
     return OBB_OK;
+}
+
+int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
+    OBB_REQUIRE(ctx, ctx && key, "obb_set_option: bad arguments");
+    std::string k(key);
+    if (k == "precision") {  // 16 = fp16 storage (default), 1016 = bf16 storage; takes effect at the next obb_model_load
+        OBB_REQUIRE(ctx, value == 16 || value == 1016, "obb_set_option: precision must be 16 (fp16) or 1016 (bf16)");
+        ctx->opt_f16 = (value == 16);
+        return OBB_OK;
+    }
+    return set_error(ctx, OBB_ERR_INVALID, "obb_set_option: unknown key '%s'", key);
 }
 
 int obb_model_info(const obb_ctx *cctx, int32_t h, int32_t w, int32_t *nc, int32_t *ch, int32_t *anchors, int32_t *nconv) {
@@ -537,8 +551,12 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
     if (shape_hwc_host) { shape_hwc_host[0] = b.H; shape_hwc_host[1] = b.W; shape_hwc_host[2] = sl.C; }
     if (!out) return OBB_OK;
     OBB_REQUIRE(ctx, max_elems >= n, "obb_debug_activation: output too small (%lld < %lld)", (long long)max_elems, (long long)n);
-    hipLaunchKernelGGL(k_bf16_slice_to_f32, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, b.per_img(), b.C,
-                       sl.co, sl.C, (int64_t)b.H * b.W, B, out);
+    if (ctx->model->f16)
+        hipLaunchKernelGGL(k_half_slice_to_f32<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p,
+                           b.per_img(), b.C, sl.co, sl.C, (int64_t)b.H * b.W, B, out);
+    else
+        hipLaunchKernelGGL(k_half_slice_to_f32<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p,
+                           b.per_img(), b.C, sl.co, sl.C, (int64_t)b.H * b.W, B, out);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

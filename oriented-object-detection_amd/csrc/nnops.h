@@ -4,8 +4,8 @@
 
 namespace obb {
 hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B,
-                          int H, int W, int C, int act, hipStream_t st);
-hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st);
+                          int H, int W, int C, int act, bool f16, hipStream_t st);
+hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, bool f16, hipStream_t st);
 hipError_t launch_upsample2(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st);
-hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, hipStream_t st);
+hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool f16, hipStream_t st);
 }  // namespace obb

@@ -6,25 +6,9 @@
 
 namespace obb {
 
-__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pk2(float a, float b) {
-    __bf16 x = (__bf16)a, y = (__bf16)b;
-    uint16_t ux, uy;
-    __builtin_memcpy(&ux, &x, 2);
-    __builtin_memcpy(&uy, &y, 2);
-    return (uint32_t)ux | ((uint32_t)uy << 16);
-}
-__device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
-    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
-    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
-}
-__device__ __forceinline__ uint4 pack8(const float *f) {
-    return make_uint4(pk2(f[0], f[1]), pk2(f[2], f[3]), pk2(f[4], f[5]), pk2(f[6], f[7]));
-}
-
 // ---------------------------------------------------------------- depthwise 3x3, stride 1, pad 1 (+bias, SiLU, +residual)
 // w: fp32 [9][C] (values already rounded to bf16), thread = (pixel, 8-channel chunk)
+template <bool F16>
 __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, TensorRef res, const float *__restrict__ w,
                                                 const float *__restrict__ bias, int B, int H, int W, int C, int act) {
     const int c8n = C >> 3;
@@ -50,7 +34,7 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
             if (xx < 0 || xx >= W) continue;
             uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yy * W + xx) * in.cs);
             float f[8];
-            unpack8(v, f);
+            unpack8<F16>(v, f);
             const float4 *wp = reinterpret_cast<const float4 *>(w + (ky * 3 + kx) * C + c8 * 8);
             float4 w0 = wp[0], w1 = wp[1];
             acc[0] += f[0] * w0.x; acc[1] += f[1] * w0.y; acc[2] += f[2] * w0.z; acc[3] += f[3] * w0.w;
@@ -70,14 +54,15 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
     if (res.p) {
         uint4 rv = *reinterpret_cast<const uint4 *>((const bf16_t *)res.p + (int64_t)b * res.bs + opix * res.cs + res.co + c8 * 8);
         float rf[8];
-        unpack8(rv, rf);
+        unpack8<F16>(rv, rf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += rf[j];
     }
-    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + opix * out.cs + out.co + c8 * 8) = pack8(acc);
+    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + opix * out.cs + out.co + c8 * 8) = pack8<F16>(acc);
 }
 
 // ---------------------------------------------------------------- MaxPool2d(k=5, s=1, p=2)  (implicit -inf padding)
+template <bool F16>
 __global__ __launch_bounds__(256) void k_maxpool5(TensorRef in, TensorRef out, int B, int H, int W, int C) {
     const int c8n = C >> 3;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -96,11 +81,11 @@ __global__ __launch_bounds__(256) void k_maxpool5(TensorRef in, TensorRef out, i
         for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) {
             uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yy * W + xx) * in.cs);
             float f[8];
-            unpack8(v, f);
+            unpack8<F16>(v, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
         }
-    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + ((int64_t)y * W + x) * out.cs + out.co + c8 * 8) = pack8(m);
+    *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + ((int64_t)y * W + x) * out.cs + out.co + c8 * 8) = pack8<F16>(m);
 }
 
 // ---------------------------------------------------------------- nearest-neighbour x2 upsample (pure copy)
@@ -123,7 +108,7 @@ __global__ __launch_bounds__(256) void k_upsample2(TensorRef in, TensorRef out, 
 // qkv slice layout per token (channels permuted by the weight loader): [q: nh*KD][k: nh*KD][v: nh*HD].
 // One workgroup per (tile, head): K and V of all N tokens live in LDS as fp32; a thread owns query rows.
 // out[n, h*HD + d] = sum_m softmax_m(q_n . k_m * scale) * v_m[d]   (two-pass softmax in fp32, like torch.softmax)
-template <int KD, int HD>
+template <int KD, int HD, bool F16>
 __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out, int N, int nh, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *sk = sm;                      // [N][KD+1]
@@ -134,7 +119,7 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
         int n = i / (KD / 8), c = i % (KD / 8);
         uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + nh * KD + h * KD + c * 8);
         float f[8];
-        unpack8(v, f);
+        unpack8<F16>(v, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sk[n * (KD + 1) + c * 8 + j] = f[j];
     }
@@ -142,7 +127,7 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
         int n = i / (HD / 8), c = i % (HD / 8);
         uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + 2 * nh * KD + h * HD + c * 8);
         float f[8];
-        unpack8(v, f);
+        unpack8<F16>(v, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sv[n * HD + c * 8 + j] = f[j];
     }
@@ -152,7 +137,7 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
 #pragma unroll
         for (int c = 0; c < KD / 8; ++c) {
             uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)n * qkv.cs + h * KD + c * 8);
-            unpack8(v, &q[c * 8]);
+            unpack8<F16>(v, &q[c * 8]);
         }
         float mx = -INFINITY;
         for (int m = 0; m < N; ++m) {
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = acc[c * 8 + j] * inv;
-            *reinterpret_cast<uint4 *>(op + c * 8) = pack8(f);
+            *reinterpret_cast<uint4 *>(op + c * 8) = pack8<F16>(f);
         }
     }
 }
@@ -189,15 +174,19 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B,
-                          int H, int W, int C, int act, hipStream_t st) {
+                          int H, int W, int C, int act, bool f16, hipStream_t st) {
     if (C % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dwconv3, dim3(blocks_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
+    dim3 grid(blocks_for((int64_t)B * H * W * (C / 8)));
+    if (f16) hipLaunchKernelGGL(k_dwconv3<true>, grid, dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
+    else hipLaunchKernelGGL(k_dwconv3<false>, grid, dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
     return hipGetLastError();
 }
 
-hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st) {
+hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, bool f16, hipStream_t st) {
     if (C % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_maxpool5, dim3(blocks_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, st, in, out, B, H, W, C);
+    dim3 grid(blocks_for((int64_t)B * H * W * (C / 8)));
+    if (f16) hipLaunchKernelGGL(k_maxpool5<true>, grid, dim3(256), 0, st, in, out, B, H, W, C);
+    else hipLaunchKernelGGL(k_maxpool5<false>, grid, dim3(256), 0, st, in, out, B, H, W, C);
     return hipGetLastError();
 }
 
@@ -207,19 +196,24 @@ hipError_t launch_upsample2(const TensorRef &in, const TensorRef &out, int B, in
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, hipStream_t st) {
-    if (kd != 32 || hd != 64) return hipErrorInvalidValue;  // head_dim is 64 for every YOLO11 scale (heads = c/64)
-    size_t lds = sizeof(float) * ((size_t)N * (32 + 1) + (size_t)N * 64);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;  // N <= 422 tokens (input up to 640x640)
+template <bool F16>
+static hipError_t launch_attention_t(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_attention<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k_attention<32, 64, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     float scale = (float)(1.0 / sqrt((double)kd));  // python: key_dim ** -0.5 evaluated in double, applied to an fp32 tensor
-    hipLaunchKernelGGL((k_attention<32, 64>), dim3((unsigned)(B * nh)), dim3(256), lds, st, qkv, out, N, nh, scale);
+    hipLaunchKernelGGL((k_attention<32, 64, F16>), dim3((unsigned)(B * nh)), dim3(256), lds, st, qkv, out, N, nh, scale);
     return hipGetLastError();
+}
+
+hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool f16, hipStream_t st) {
+    if (kd != 32 || hd != 64) return hipErrorInvalidValue;  // head_dim is 64 for every YOLO11 scale (heads = c/64)
+    size_t lds = sizeof(float) * ((size_t)N * (32 + 1) + (size_t)N * 64);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;  // N <= 422 tokens (input up to 640x640)
+    return f16 ? launch_attention_t<true>(qkv, out, B, N, nh, kd, lds, st) : launch_attention_t<false>(qkv, out, B, N, nh, kd, lds, st);
 }
 
 }  // namespace obb

@@ -166,9 +166,13 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
 
 # ---------------------------------------------------------------- S1 model
 
-def model_load(blob, device=None):
-    """blob: bytes of an "OBBW" weight blob (host).  One model per context."""
+PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016}
+
+
+def model_load(blob, device=None, precision="f16"):
+    """blob: bytes of an "OBBW" weight blob (host).  One model per context.  precision: 16-bit storage type."""
     c = ctx(device)
+    _call("obb_set_option", c, b"precision", PRECISIONS[precision])
     buf = (C.c_char * len(blob)).from_buffer_copy(blob)
     _call("obb_model_load", c, buf, len(blob))
 

@@ -1,0 +1,430 @@
+// Everything the Ultralytics OBB predictor does around the network (call site Detect_OBB.py:81-83, results consumed at
+// :228-231), restated as wave64 HIP kernels in fp32 with torch's operation order (built with -ffp-contract=off):
+//   k_decode        OBB head _inference: DFL softmax-expectation, dist2rbox, angle = (sigmoid-0.25)*pi, class sigmoid
+//   k_nms_tile      non_max_suppression(rotated=True): conf filter, (conf, cls) = max over classes, class offset 7680,
+//                   stable score sort, ProbIoU Fast-NMS (keep j iff no higher-scored i with probiou >= thr), max_det
+//   k_results       construct_result: regularize_rboxes, scale_boxes(xywh=True), xywhr2xyxyxyxy
+//   k_gather_tiles / k_letterbox   the tiler's crop (Detect_OBB.py:218-220) and LetterBox(auto=True) preprocess
+// SURVEY.md Appendix A2/A4/A6.  These are HBM/latency-bound kernels: one workgroup per tile, candidates kept in
+// anchor order by ballot/prefix-sum compaction so that ties sort exactly like a stable argsort.
+#include "ctx.h"
+
+namespace obb {
+
+static constexpr int kRegMaxD = 16;
+static constexpr float kPiF = 3.14159274101257324f;      // (float)math.pi
+static constexpr float kHalfPiF = 1.57079637050628662f;  // (float)(math.pi / 2)
+static constexpr float kMaxWh = 7680.0f;
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------- decode
+__global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, int B, int A, int nc, int h, int w,
+                                               float *__restrict__ pred) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * A) return;
+    int a = (int)(i % A);
+    const int no = 4 * kRegMaxD + nc + 1, np = 4 + nc + 1;
+    const float *hp = head + i * no;
+    // anchor of this row: levels P3, P4, P5 concatenated, row-major inside a level, centres at +0.5
+    int n8 = (h / 8) * (w / 8), n16 = (h / 16) * (w / 16);
+    int stride, lw, la;
+    if (a < n8) { stride = 8; lw = w / 8; la = a; }
+    else if (a < n8 + n16) { stride = 16; lw = w / 16; la = a - n8; }
+    else { stride = 32; lw = w / 32; la = a - n8 - n16; }
+    float ax = (float)(la % lw) + 0.5f, ay = (float)(la / lw) + 0.5f;
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float x[kRegMaxD];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kRegMaxD; ++k) { x[k] = hp[s * kRegMaxD + k]; m = fmaxf(m, x[k]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRegMaxD; ++k) { x[k] = expf(x[k] - m); sum += x[k]; }
+        float e = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRegMaxD; ++k) e += (x[k] / sum) * (float)k;
+        d[s] = e;
+    }
+    float ang = (sigmoid_f(hp[4 * kRegMaxD + nc]) - 0.25f) * kPiF;
+    float c = cosf(ang), s = sinf(ang);
+    float xf = (d[2] - d[0]) / 2.0f, yf = (d[3] - d[1]) / 2.0f;
+    float x = xf * c - yf * s, y = xf * s + yf * c;
+    float fs = (float)stride;
+    float *pp = pred + i * np;
+    pp[0] = (x + ax) * fs;
+    pp[1] = (y + ay) * fs;
+    pp[2] = (d[0] + d[2]) * fs;
+    pp[3] = (d[1] + d[3]) * fs;
+    for (int k = 0; k < nc; ++k) pp[4 + k] = sigmoid_f(hp[4 * kRegMaxD + k]);
+    pp[4 + nc] = ang;
+}
+
+// ---------------------------------------------------------------------------------------------- ProbIoU
+struct RBox { float x, y, A, B, C, det; };  // offset centre + covariance terms (batch_probiou / _get_covariance_matrix)
+
+__device__ __forceinline__ RBox make_rbox(float x, float y, float w, float h, float t) {
+    RBox r;
+    float a = w * w / 12.0f, b = h * h / 12.0f;
+    float c = cosf(t), s = sinf(t);
+    float c2 = c * c, s2 = s * s;
+    r.x = x; r.y = y;
+    r.A = a * c2 + b * s2;
+    r.B = a * s2 + b * c2;
+    r.C = (a - b) * c * s;
+    float dd = r.A * r.B - r.C * r.C;
+    r.det = dd > 0.0f ? dd : 0.0f;
+    return r;
+}
+
+__device__ __forceinline__ float probiou(const RBox &p, const RBox &q) {
+    const float eps = 1e-7f;
+    float sa = p.A + q.A, sb = p.B + q.B, sc = p.C + q.C;
+    float den = sa * sb - sc * sc;
+    float dy = p.y - q.y, dx = p.x - q.x;
+    float t1 = ((sa * (dy * dy) + sb * (dx * dx)) / (den + eps)) * 0.25f;
+    float t2 = ((sc * (q.x - p.x) * dy) / (den + eps)) * 0.5f;
+    float t3 = logf(den / (4.0f * sqrtf(p.det * q.det) + eps) + eps) * 0.5f;
+    float bd = t1 + t2 + t3;
+    bd = bd < eps ? eps : (bd > 100.0f ? 100.0f : bd);
+    float hd = sqrtf(1.0f - expf(-bd) + eps);
+    return 1.0f - hd;
+}
+
+// block-wide ordered compaction helper: returns this thread's output slot (or -1) and advances *base by the chunk total
+__device__ __forceinline__ int ordered_slot(bool flag, int *wave_tot /* LDS[4] */, int &base) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long bal = __ballot(flag);
+    int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (k < wave) off += wave_tot[k]; tot += wave_tot[k]; }
+    int slot = flag ? base + off + before : -1;
+    base += tot;
+    __syncthreads();
+    return slot;
+}
+
+struct NmsScratch {  // per tile, capacity A rows each
+    int32_t *cand;   // anchor index of candidate k (anchor order)
+    float *cscore;   // its confidence
+    int32_t *ccls;
+    int32_t *order;  // sorted position -> candidate k
+    RBox *rb;        // sorted order
+    uint8_t *keep;   // sorted order
+};
+
+// One workgroup per tile.
+__global__ __launch_bounds__(256) void k_nms_tile(const float *__restrict__ pred, int A, int nc, float conf_thres, float iou_thres,
+                                                 int max_det, int max_nms, NmsScratch S, float *__restrict__ out,
+                                                 int32_t *__restrict__ count) {
+    __shared__ int wave_tot[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int np = 4 + nc + 1;
+    const float *pb = pred + (int64_t)b * A * np;
+    int32_t *cand = S.cand + (int64_t)b * A;
+    float *cscore = S.cscore + (int64_t)b * A;
+    int32_t *ccls = S.ccls + (int64_t)b * A;
+    int32_t *order = S.order + (int64_t)b * A;
+    RBox *rb = S.rb + (int64_t)b * A;
+    uint8_t *keep = S.keep + (int64_t)b * A;
+
+    // 1. candidates in anchor order: conf = max over classes (first maximum), conf > conf_thres
+    int n = 0;
+    for (int a0 = 0; a0 < A; a0 += 256) {
+        int a = a0 + tid;
+        float best = -INFINITY;
+        int bj = 0;
+        if (a < A) {
+            const float *cp = pb + (int64_t)a * np + 4;
+            for (int j = 0; j < nc; ++j) { float v = cp[j]; if (v > best) { best = v; bj = j; } }
+        }
+        bool flag = (a < A) && (best > conf_thres);
+        int slot = ordered_slot(flag, wave_tot, n);
+        if (flag) { cand[slot] = a; cscore[slot] = best; ccls[slot] = bj; }
+    }
+    __syncthreads();
+    if (n == 0) { if (tid == 0) count[b] = 0; return; }
+
+    // 2. stable descending rank sort by confidence (torch.argsort(descending=True, stable) restated); n > max_nms keeps the top max_nms
+    for (int i = tid; i < n; i += 256) {
+        float si = cscore[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { float sj = cscore[j]; rank += (sj > si) | ((sj == si) & (j < i)); }
+        order[rank] = i;
+    }
+    __syncthreads();
+    if (n > max_nms) n = max_nms;
+    for (int r = tid; r < n; r += 256) {
+        int k = order[r];
+        const float *pp = pb + (int64_t)cand[k] * np;
+        float c = (float)ccls[k] * kMaxWh;  // class offset: boxes of different classes never overlap
+        rb[r] = make_rbox(pp[0] + c, pp[1] + c, pp[2], pp[3], pp[4 + nc]);
+    }
+    __syncthreads();
+
+    // 3. Fast-NMS: keep r iff no i < r with probiou(i, r) >= thr  (suppressed boxes still suppress)
+    const bool skip_other_cls = iou_thres > 1e-3f;  // offset boxes of another class have probiou ~ 0
+    for (int r = tid; r < n; r += 256) {
+        RBox q = rb[r];
+        int cq = ccls[order[r]];
+        bool k = true;
+        for (int i = 0; i < r; ++i) {
+            if (skip_other_cls && ccls[order[i]] != cq) continue;
+            if (probiou(rb[i], q) >= iou_thres) { k = false; break; }
+        }
+        keep[r] = (uint8_t)k;
+    }
+    __syncthreads();
+
+    // 4. first max_det survivors in score order -> rows (x, y, w, h, conf, cls, theta)
+    int m = 0;
+    float *ob = out + (int64_t)b * max_det * 7;
+    for (int r0 = 0; r0 < n && m < max_det; r0 += 256) {
+        int r = r0 + tid;
+        bool flag = (r < n) && keep[r];
+        int slot = ordered_slot(flag, wave_tot, m);
+        if (flag && slot < max_det) {
+            int k = order[r];
+            const float *pp = pb + (int64_t)cand[k] * np;
+            float *o = ob + (int64_t)slot * 7;
+            o[0] = pp[0]; o[1] = pp[1]; o[2] = pp[2]; o[3] = pp[3];
+            o[4] = cscore[k]; o[5] = (float)ccls[k]; o[6] = pp[4 + nc];
+        }
+    }
+    if (tid == 0) count[b] = m < max_det ? m : max_det;
+}
+
+// stand-alone Fast-NMS on a caller-provided candidate list (parity tap): boxes [n,5], scores [n]
+__global__ __launch_bounds__(256) void k_probiou_nms_list(const float *__restrict__ boxes, const float *__restrict__ scores, int n, float thr,
+                                                         int32_t *__restrict__ order, uint8_t *__restrict__ keep, RBox *__restrict__ rb) {
+    // single workgroup, grid-stride over candidates
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float si = scores[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { float sj = scores[j]; rank += (sj > si) | ((sj == si) & (j < i)); }
+        order[rank] = i;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const float *p = boxes + (int64_t)order[r] * 5;
+        rb[r] = make_rbox(p[0], p[1], p[2], p[3], p[4]);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256) {
+        RBox q = rb[r];
+        bool k = true;
+        for (int i = 0; i < r; ++i)
+            if (probiou(rb[i], q) >= thr) { k = false; break; }
+        keep[r] = (uint8_t)k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- results
+__device__ __forceinline__ float py_remainder(float a, float b) {  // torch.remainder / Python % for b > 0
+    float r = fmodf(a, b);
+    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_results(const float *__restrict__ det, const float *__restrict__ lb, int64_t n,
+                                                float *__restrict__ xywhr, float *__restrict__ pts) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *d = det + i * 7;
+    float x = d[0], y = d[1], w = d[2], h = d[3], t = d[6];
+    bool swap = py_remainder(t, kPiF) >= kHalfPiF;  // regularize_rboxes
+    float w_ = swap ? h : w, h_ = swap ? w : h;
+    t = py_remainder(t, kHalfPiF);
+    if (lb) {  // scale_boxes(xywh=True): subtract the letterbox pad, divide by the gain
+        float gain = lb[i * 3], px = lb[i * 3 + 1], py = lb[i * 3 + 2];
+        x -= px; y -= py;
+        x /= gain; y /= gain; w_ /= gain; h_ /= gain;
+    }
+    xywhr[i * 5] = x; xywhr[i * 5 + 1] = y; xywhr[i * 5 + 2] = w_; xywhr[i * 5 + 3] = h_; xywhr[i * 5 + 4] = t;
+    float c = cosf(t), s = sinf(t);  // xywhr2xyxyxyxy
+    float v1x = w_ / 2.0f * c, v1y = w_ / 2.0f * s;
+    float v2x = -h_ / 2.0f * s, v2y = h_ / 2.0f * c;
+    float *p = pts + i * 8;
+    p[0] = x + v1x + v2x; p[1] = y + v1y + v2y;
+    p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
+    p[4] = x - v1x - v2x; p[5] = y - v1y - v2y;
+    p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
+}
+
+// ---------------------------------------------------------------------------------------------- tiler crops / letterbox
+__global__ __launch_bounds__(256) void k_gather_tiles(const uint8_t *__restrict__ img, int H, int W, int C, const int32_t *__restrict__ rects,
+                                                     int tile, uint8_t *__restrict__ out) {
+    // grid: (row chunks, tile rows, ntiles); a thread copies 4 consecutive bytes of a tile row
+    int t = blockIdx.z, row = blockIdx.y;
+    int rowbytes = tile * C;
+    int x0 = rects[4 * t], y0 = rects[4 * t + 1];
+    const uint8_t *src = img + ((int64_t)(y0 + row) * W + x0) * C;
+    uint8_t *dst = out + ((int64_t)t * tile + row) * rowbytes;
+    int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < rowbytes) {
+        uint32_t v = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+        *reinterpret_cast<uint32_t *>(dst + i) = v;
+    } else {
+        for (int k = i; k < rowbytes; ++k) dst[k] = src[k];
+    }
+}
+
+struct LbParams { int x, y, cw, ch, new_w, new_h, top, left, out_h, out_w, resize; double sx, sy; };
+
+__device__ __forceinline__ void lin_coeff(int d, double scale, int n_src, int &s, int &a1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);  // OpenCV: double expression, stored to float
+    int fl = (int)floorf(f);
+    f -= (float)fl;
+    if (fl < 0) { fl = 0; f = 0.f; }
+    if (fl >= n_src - 1) { fl = n_src - 1; f = 0.f; }
+    s = fl;
+    a1 = (int)rintf(f * 2048.0f);
+}
+
+__global__ __launch_bounds__(256) void k_letterbox(const uint8_t *__restrict__ img, int H, int W, int C, LbParams P, uint8_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)P.out_h * P.out_w) return;
+    int ox = (int)(i % P.out_w), oy = (int)(i / P.out_w);
+    int rx = ox - P.left, ry = oy - P.top;
+    uint8_t *o = out + i * C;
+    if (rx < 0 || ry < 0 || rx >= P.new_w || ry >= P.new_h) {
+        for (int c = 0; c < C; ++c) o[c] = 114;
+        return;
+    }
+    if (!P.resize) {
+        const uint8_t *s = img + ((int64_t)(P.y + ry) * W + P.x + rx) * C;
+        for (int c = 0; c < C; ++c) o[c] = s[c];
+        return;
+    }
+    // cv2.resize INTER_LINEAR for 8-bit: 11-bit fixed-point coefficients, half-pixel centres (restated; cv2 absent)
+    int sx0, ax1, sy0, ay1;
+    lin_coeff(rx, P.sx, P.cw, sx0, ax1);
+    lin_coeff(ry, P.sy, P.ch, sy0, ay1);
+    int sx1 = min(sx0 + 1, P.cw - 1), sy1 = min(sy0 + 1, P.ch - 1);
+    int ax0 = 2048 - ax1, ay0 = 2048 - ay1;
+    const uint8_t *r0 = img + ((int64_t)(P.y + sy0) * W + P.x) * C, *r1 = img + ((int64_t)(P.y + sy1) * W + P.x) * C;
+    for (int c = 0; c < C; ++c) {
+        long long top = (long long)r0[sx0 * C + c] * ax0 + (long long)r0[sx1 * C + c] * ax1;
+        long long bot = (long long)r1[sx0 * C + c] * ax0 + (long long)r1[sx1 * C + c] * ax1;
+        long long v = (top * ay0 + bot * ay1 + (1ll << 21)) >> 22;
+        o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+static int nms_scratch(obb_ctx *ctx, int B, int A, NmsScratch &S) {
+    size_t rows = (size_t)B * A;
+    S.cand = (int32_t *)ctx->workspace(WS_NMS_A, rows * 4);
+    S.cscore = (float *)ctx->workspace(WS_NMS_B, rows * 4);
+    S.ccls = (int32_t *)ctx->workspace(WS_NMS_C, rows * 4);
+    S.order = (int32_t *)ctx->workspace(WS_NMS_D, rows * 4);
+    S.rb = (RBox *)ctx->workspace(WS_GEOM_A, rows * sizeof(RBox));
+    S.keep = (uint8_t *)ctx->workspace(WS_GEOM_B, rows);
+    if (!S.cand || !S.cscore || !S.ccls || !S.order || !S.rb || !S.keep) return set_error(ctx, OBB_ERR_HIP, "NMS workspace allocation failed");
+    return OBB_OK;
+}
+
+}  // namespace obb
+
+using namespace obb;
+
+extern "C" {
+
+int obb_decode(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float *pred, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0 && h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0, "obb_decode: bad arguments");
+    int32_t nc = 0, A = 0;
+    int rc = obb_model_info(ctx, h, w, &nc, nullptr, &A, nullptr);
+    if (rc) return rc;
+    if (B == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, head && pred, "obb_decode: NULL buffer");
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)s, head, B, A, nc, h, w, pred);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres, int32_t max_det,
+                   float *out, int32_t *count, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0 && max_det > 0, "obb_decode_nms: bad arguments");
+    int32_t nc = 0, A = 0;
+    int rc = obb_model_info(ctx, h, w, &nc, nullptr, &A, nullptr);
+    if (rc) return rc;
+    if (B == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, head && out && count, "obb_decode_nms: NULL buffer");
+    float *pred = (float *)ctx->workspace(WS_GEOM_C, sizeof(float) * (size_t)B * A * (4 + nc + 1));
+    if (!pred) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
+    NmsScratch S;
+    rc = nms_scratch(ctx, B, A, S);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, st, head, B, A, nc, h, w, pred);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_nms_tile, dim3((unsigned)B), dim3(256), 0, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det, 30000, S, out,
+                       count);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_probiou_nms(obb_ctx *ctx, const float *boxes, const float *scores, int64_t n, float iou_thres, int32_t *order, uint8_t *keep,
+                    obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1 << 24), "obb_probiou_nms: bad n");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, boxes && scores && order && keep, "obb_probiou_nms: NULL buffer");
+    RBox *rb = (RBox *)ctx->workspace(WS_GEOM_A, sizeof(RBox) * (size_t)n);
+    if (!rb) return set_error(ctx, OBB_ERR_HIP, "obb_probiou_nms: workspace allocation failed");
+    hipLaunchKernelGGL(k_probiou_nms_list, dim3(1), dim3(256), 0, (hipStream_t)s, boxes, scores, (int)n, iou_thres, order, keep, rb);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_results(obb_ctx *ctx, const float *det, const float *lb, int64_t n, float *xywhr, float *pts, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_results: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, det && xywhr && pts, "obb_results: NULL buffer");
+    hipLaunchKernelGGL(k_results, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, det, lb, n, xywhr, pts);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_gather_tiles(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, const int32_t *rects, int32_t ntiles,
+                     int32_t tile, uint8_t *tiles_out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && H > 0 && W > 0 && (C == 3 || C == 4) && ntiles >= 0 && tile > 0 && tile <= H && tile <= W,
+                "obb_gather_tiles: bad arguments");
+    if (ntiles == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, image && rects && tiles_out, "obb_gather_tiles: NULL buffer");
+    OBB_REQUIRE(ctx, ntiles <= 65535 && tile <= 65535, "obb_gather_tiles: too many tiles in one call");
+    int rowbytes = tile * C;
+    dim3 grid((unsigned)cdiv(cdiv(rowbytes, 4), 256), (unsigned)tile, (unsigned)ntiles);
+    hipLaunchKernelGGL(k_gather_tiles, grid, dim3(256), 0, (hipStream_t)s, image, H, W, C, rects, tile, tiles_out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_letterbox(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, int32_t x, int32_t y, int32_t x2, int32_t y2,
+                  int32_t imgsz, uint8_t *out, int32_t out_h, int32_t out_w, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && image && out && (C == 3 || C == 4) && x >= 0 && y >= 0 && x2 > x && y2 > y && x2 <= W && y2 <= H && imgsz > 0,
+                "obb_letterbox: bad arguments");
+    int ch = y2 - y, cw = x2 - x;
+    double r = std::min((double)imgsz / ch, (double)imgsz / cw);
+    LbParams P;
+    P.x = x; P.y = y; P.cw = cw; P.ch = ch;
+    P.new_w = (int)std::nearbyint(cw * r);  // Python round(): ties to even
+    P.new_h = (int)std::nearbyint(ch * r);
+    int dw = ((imgsz - P.new_w) % 32 + 32) % 32, dh = ((imgsz - P.new_h) % 32 + 32) % 32;
+    double hw = dw / 2.0, hh = dh / 2.0;
+    P.top = (int)std::nearbyint(hh - 0.1); P.left = (int)std::nearbyint(hw - 0.1);
+    int bottom = (int)std::nearbyint(hh + 0.1), right = (int)std::nearbyint(hw + 0.1);
+    P.out_h = P.new_h + P.top + bottom; P.out_w = P.new_w + P.left + right;
+    OBB_REQUIRE(ctx, P.out_h == out_h && P.out_w == out_w, "obb_letterbox: output must be %dx%d for this crop, got %dx%d", P.out_h, P.out_w,
+                out_h, out_w);
+    P.resize = (P.new_w != cw || P.new_h != ch);
+    P.sx = (double)cw / P.new_w; P.sy = (double)ch / P.new_h;
+    hipLaunchKernelGGL(k_letterbox, dim3((unsigned)cdiv((int64_t)out_h * out_w, 256)), dim3(256), 0, (hipStream_t)s, image, H, W, C, P, out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+}  // extern "C"

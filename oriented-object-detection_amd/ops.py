@@ -204,3 +204,79 @@ def debug_activation(name, B, h, w, device=None):
     out = torch.empty((B, shp[0], shp[1], shp[2]), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
     _call("obb_debug_activation", c, h, w, B, name.encode(), _p(out), out.numel(), C.byref(n), shp, _stream())
     return out
+
+
+def decode(head, h, w):
+    """raw head [B,A,64+nc+1] -> predictions [B,A,4+nc+1] (x,y,w,h, class scores, theta); anchor-major."""
+    hd = _chk(head, torch.float32, "head")
+    B, A, no = hd.shape
+    pred = torch.empty((B, A, no - 64 + 4), dtype=torch.float32, device=hd.device)
+    _call("obb_decode", ctx(hd.device), _p(hd), B, h, w, _p(pred), _stream())
+    return pred
+
+
+def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300):
+    """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B])"""
+    hd = _chk(head, torch.float32, "head")
+    B = hd.shape[0]
+    det = torch.zeros((B, max_det, 7), dtype=torch.float32, device=hd.device)
+    count = torch.zeros(B, dtype=torch.int32, device=hd.device)
+    _call("obb_decode_nms", ctx(hd.device), _p(hd), B, h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
+    return det, count
+
+
+def probiou_nms(boxes, scores, iou):
+    b = _chk(boxes, torch.float32, "boxes").reshape(-1, 5)
+    s = _chk(scores, torch.float32, "scores")
+    n = b.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=b.device)
+    keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
+    _call("obb_probiou_nms", ctx(b.device), _p(b), _p(s), n, float(iou), _p(order), _p(keep), _stream())
+    return order, keep
+
+
+def results(det, lb=None):
+    """det [n,7] rows from decode_nms -> (xywhr [n,5] regularised + un-letterboxed, corners [n,8])"""
+    d = _chk(det, torch.float32, "det").reshape(-1, 7)
+    n = d.shape[0]
+    if lb is not None:
+        lb = _chk(lb, torch.float32, "lb").reshape(-1, 3)
+    xywhr = torch.empty((n, 5), dtype=torch.float32, device=d.device)
+    pts = torch.empty((n, 8), dtype=torch.float32, device=d.device)
+    _call("obb_results", ctx(d.device), _p(d), _p(lb), n, _p(xywhr), _p(pts), _stream())
+    return xywhr, pts
+
+
+def gather_tiles(image, rects, tile):
+    """image uint8 [H,W,C] (device), rects int32 [n,4] (device, all tile x tile) -> uint8 [n,tile,tile,C]"""
+    img = _chk(image, torch.uint8, "image")
+    r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
+    H, W, Cc = img.shape
+    out = torch.empty((r.shape[0], tile, tile, Cc), dtype=torch.uint8, device=img.device)
+    _call("obb_gather_tiles", ctx(img.device), _p(img), H, W, Cc, _p(r), r.shape[0], tile, _p(out), _stream())
+    return out
+
+
+def letterbox_shape(ch, cw, imgsz, stride=32):
+    """Host arithmetic of LetterBox(auto=True): -> dict(out_h, out_w, gain, pad_x, pad_y)"""
+    r = min(imgsz / ch, imgsz / cw)
+    new_w, new_h = int(round(cw * r)), int(round(ch * r))
+    dw, dh = ((imgsz - new_w) % stride) / 2, ((imgsz - new_h) % stride) / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    out_h, out_w = new_h + top + bottom, new_w + left + right
+    # un-letterbox parameters exactly as scale_boxes computes them from the two shapes (SURVEY Appendix A2)
+    gain = min(out_h / ch, out_w / cw)
+    pad_x = round((out_w - cw * gain) / 2 - 0.1)
+    pad_y = round((out_h - ch * gain) / 2 - 0.1)
+    return {"out_h": out_h, "out_w": out_w, "gain": gain, "pad_x": pad_x, "pad_y": pad_y}
+
+
+def letterbox(image, x, y, x2, y2, imgsz):
+    img = _chk(image, torch.uint8, "image")
+    H, W, Cc = img.shape
+    p = letterbox_shape(y2 - y, x2 - x, imgsz)
+    out = torch.empty((p["out_h"], p["out_w"], Cc), dtype=torch.uint8, device=img.device)
+    _call("obb_letterbox", ctx(img.device), _p(img), H, W, Cc, int(x), int(y), int(x2), int(y2), int(imgsz), _p(out), p["out_h"],
+          p["out_w"], _stream())
+    return out, p

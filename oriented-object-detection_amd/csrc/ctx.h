@@ -22,7 +22,9 @@ struct obb_ctx {
     // grow-only device scratch, one slot per purpose so that concurrent users inside one call never alias
     struct Slot { void *p = nullptr; size_t bytes = 0; };
     std::vector<Slot> ws;
-    std::shared_ptr<obb::Model> model;
+    std::shared_ptr<obb::Model> model;                   // model of the active slot
+    std::map<int, std::shared_ptr<obb::Model>> slots;    // parked models (obb_set_option "model_slot")
+    int slot = 0;
     bool opt_f16 = true;
     void *workspace(int slot, size_t bytes);
     ~obb_ctx();

@@ -506,6 +506,15 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_f16 = (value == 16);
         return OBB_OK;
     }
+    if (k == "model_slot") {  // several models per context (dual-scale 128 + 416): select which one load/forward address
+        OBB_REQUIRE(ctx, value >= 0 && value < 64, "obb_set_option: model_slot must be in [0, 64)");
+        if ((int)value != ctx->slot) {
+            ctx->slots[ctx->slot] = ctx->model;
+            ctx->model = ctx->slots[(int)value];
+            ctx->slot = (int)value;
+        }
+        return OBB_OK;
+    }
     return set_error(ctx, OBB_ERR_INVALID, "obb_set_option: unknown key '%s'", key);
 }
 

@@ -1,0 +1,138 @@
+"""`YOLO(...)` / `model(img, conf=...)` / `results[0].obb` -- the slice of the Ultralytics API that Detect_OBB.py uses
+(:16, :26, :81-83, :228-231), backed by libobbhip.so.  Same names, argument meaning and result accessors; the
+network, decode, NMS and result construction all run as HIP kernels.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class OBB:
+    """Mirror of ultralytics.engine.results.OBB for the accessors the reference touches: iteration / indexing yield
+    1-row views exposing .xyxyxyxy (1,4,2), .cls (1,), .conf (1,); plus .xywhr, .data, len()."""
+
+    def __init__(self, data, pts):
+        self.data = data  # [n,7] (x, y, w, h, theta, conf, cls)  float32, device
+        self._pts = pts   # [n,8]
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, int):
+            i = slice(i, i + 1) if i >= 0 else slice(len(self) + i, len(self) + i + 1)
+        return OBB(self.data[i], self._pts[i])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    @property
+    def xywhr(self):
+        return self.data[:, :5]
+
+    @property
+    def conf(self):
+        return self.data[:, 5]
+
+    @property
+    def cls(self):
+        return self.data[:, 6]
+
+    @property
+    def xyxyxyxy(self):
+        return self._pts.view(-1, 4, 2)
+
+    def cpu(self):
+        return OBB(self.data.cpu(), self._pts.cpu())
+
+
+class Results:
+    def __init__(self, obb, orig_shape, names=None):
+        self.obb = obb
+        self.orig_shape = orig_shape
+        self.names = names or {}
+        self.boxes = None
+
+    def __len__(self):
+        return len(self.obb)
+
+
+class YOLO:
+    """model = YOLO(weights); results = model(crop_bgr_uint8, conf=0.25)
+
+    weights: path to an "OBBW" blob, raw bytes, or any object with .to_blob() (the trained .pt files of the reference are
+    Google-Drive links and need ultralytics to un-pickle: not available offline).
+    imgsz: the size the checkpoint was trained at (Ultralytics reads it from the checkpoint: 416 / 128 here)."""
+
+    def __init__(self, weights, imgsz=416, device=None, precision="f16", names=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("YOLO: no HIP device visible; this implementation has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        if hasattr(weights, "to_blob"):
+            blob = weights.to_blob()
+        elif isinstance(weights, (bytes, bytearray)):
+            blob = bytes(weights)
+        else:
+            if not os.path.exists(weights):
+                raise FileNotFoundError(f"{weights}: weight blob not found (no download is ever attempted)")
+            with open(weights, "rb") as f:
+                blob = f.read()
+        self._blob = blob
+        self.precision = precision
+        self.imgsz = int(imgsz)
+        self.names = names or {}
+        self._load()
+
+    _next_slot = {}  # per device: every YOLO object owns one model slot of the device's libobbhip context
+
+    def _load(self):
+        idx = self.device.index
+        self._slot = YOLO._next_slot.get(idx, 0)
+        YOLO._next_slot[idx] = self._slot + 1
+        with torch.cuda.device(self.device):
+            ops.select_model(self._slot, self.device)
+            ops.model_load(self._blob, self.device, self.precision)
+            info = ops.model_info(self.imgsz, self.imgsz, self.device)
+        self.nc, self.ch = info["nc"], info["ch"]
+
+    def _ensure_active(self):
+        ops.select_model(self._slot, self.device)
+
+    # ------------------------------------------------------------------ batched device API
+    def predict_tiles(self, tiles, conf=0.25, iou=0.7, max_det=300):
+        """tiles uint8 [B,h,w,ch] on device, already letterboxed -> (det [B,max_det,7] (x,y,w,h,conf,cls,theta), count [B])"""
+        self._ensure_active()
+        B, h, w, ch = tiles.shape
+        head = ops.forward(tiles)
+        return ops.decode_nms(head, h, w, conf, iou, max_det)
+
+    # ------------------------------------------------------------------ Ultralytics-shaped API
+    def __call__(self, source, conf=0.25, iou=0.7, max_det=300, **kwargs):
+        return self.predict(source, conf=conf, iou=iou, max_det=max_det, **kwargs)
+
+    def predict(self, source, conf=0.25, iou=0.7, max_det=300, **kwargs):
+        self._ensure_active()
+        imgs = source if isinstance(source, (list, tuple)) else [source]
+        out = []
+        with torch.cuda.device(self.device):
+            for im in imgs:
+                if isinstance(im, np.ndarray):
+                    if im.dtype != np.uint8 or im.ndim != 3:
+                        raise ValueError("predict: expected an HxWxC uint8 array (as Detect_OBB.py passes crops)")
+                    im = torch.as_tensor(np.ascontiguousarray(im)).to(self.device)
+                H, W, C = im.shape
+                if C != self.ch:
+                    raise ValueError(f"predict: model expects {self.ch} channels, got {C}")
+                lbimg, p = ops.letterbox(im.contiguous(), 0, 0, W, H, self.imgsz)
+                det, count = self.predict_tiles(lbimg[None], conf, iou, max_det)
+                n = int(count[0].item())
+                rows = det[0, :n].contiguous()
+                lb = torch.tensor([[p["gain"], p["pad_x"], p["pad_y"]]], dtype=torch.float32, device=self.device).repeat(max(n, 1), 1)[:n]
+                xywhr, pts = ops.results(rows, lb.contiguous() if n else None)
+                data = torch.cat([xywhr, rows[:, 4:6]], 1)  # (x,y,w,h,theta,conf,cls)
+                out.append(Results(OBB(data, pts), (H, W), self.names))
+        return out

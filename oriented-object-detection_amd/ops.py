@@ -169,8 +169,13 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
 PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016}
 
 
+def select_model(slot, device=None):
+    """Several models can live in one context (dual-scale); choose which one load/forward/decode address."""
+    _call("obb_set_option", ctx(device), b"model_slot", int(slot))
+
+
 def model_load(blob, device=None, precision="f16"):
-    """blob: bytes of an "OBBW" weight blob (host).  One model per context.  precision: 16-bit storage type."""
+    """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: 16-bit storage type."""
     c = ctx(device)
     _call("obb_set_option", c, b"precision", PRECISIONS[precision])
     buf = (C.c_char * len(blob)).from_buffer_copy(blob)

@@ -1,0 +1,126 @@
+"""GPU parity of the assembled hot path (detect_symbols / process_image) behind the reference's own call surface."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import pipeline as opl
+from oracle.yolo11_obb import Yolo11OBB
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ood():
+    assert torch.cuda.is_available()
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import detect, model, ops
+
+    class NS:
+        pass
+    ns = NS()
+    ns.detect, ns.model, ns.ops = detect, model, ops
+    return ns
+
+
+@pytest.fixture(scope="module")
+def nets(ood):
+    n416 = Yolo11OBB("n", nc=12, ch=3, seed=0)
+    n128 = Yolo11OBB("n", nc=12, ch=3, seed=1)
+    return {"n416": n416, "n128": n128, "m416": ood.model.YOLO(n416, imgsz=416), "m128": ood.model.YOLO(n128, imgsz=128)}
+
+
+def test_reference_surface_with_foreign_model_matches_goldens(ood):
+    """detect_symbols driven by a duck-typed Ultralytics-like model reproduces the reference's own outputs exactly."""
+    cases = json.load(open(os.path.join(GOLDEN, "detect_symbols_cases.json")))
+    for c in cases:
+        img = synth.coord_image(c["H"], c["W"])
+        dets = ood.detect.detect_symbols(img, synth.StubModel(c["seed"]), c["tile"], c["overlap"])
+        exp = c["dets"]
+        assert len(dets) == len(exp)
+        for d, e in zip(dets, exp):
+            assert list(d[:10]) == e[:10]
+            assert abs(d[10] - e[10]) <= 1e-9
+
+
+def test_list_api_matches_reference_goldens(ood, ref_vectors):
+    rv = ref_vectors
+    dets = synth.dets_to_tuples(rv["merge3_boxes"], rv["merge3_cls"], rv["merge3_conf"])
+    kept = ood.detect.merge_detections(dets, float(rv["merge3_thr"]))
+    assert [int(d[10]) for d in dets] == list(rv["merge3_sorted"])  # in-place sort side effect (Detect_OBB.py:183)
+    assert [int(d[10]) for d in kept] == list(rv["merge3_kept"])
+    assert ood.detect.merge_detections([], 0.4) == []
+    ci = 3
+    d1 = synth.dets_to_tuples(rv[f"cons{ci}_b1"].reshape(-1, 8), rv[f"cons{ci}_c1"], rv[f"cons{ci}_s1"], 0)
+    d2 = synth.dets_to_tuples(rv[f"cons{ci}_b2"].reshape(-1, 8), rv[f"cons{ci}_c2"], rv[f"cons{ci}_s2"], 100000)
+    kept = ood.detect.cross_scale_consensus_filter({128: d1, 416: d2})
+    assert [int(d[10]) for d in kept] == list(rv[f"cons{ci}_kept"])
+    assert ood.detect.cross_scale_consensus_filter({}) == []
+    sq = [0, 0, 1, 0, 1, 1, 0, 1]
+    assert ood.detect.compute_polygon_iou(sq, [0.5, 0, 1.5, 0, 1.5, 1, 0.5, 1]) == pytest.approx(1 / 3, abs=1e-15)
+    assert ood.detect.compute_polygon_iou(sq, [0, 0, 1, 1, 1, 0, 0, 1]) == 0.0
+
+
+def _compare_dets(got, exp, tol_px=2e-3):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for g, e in zip(got, exp):
+        assert g[8] == e[8]
+        assert g[9] == e[9]  # confidence is selected, never recomputed: exact
+        assert max(abs(a - b) for a, b in zip(g[:8], e[:8])) < tol_px
+        assert abs(g[10] - e[10]) < 1e-2
+
+
+def test_yolo_call_surface(ood, nets):
+    """model(crop, conf=...)[0].obb: iteration yields 1-row items with .xyxyxyxy / .cls / .conf like Detect_OBB.py:228-231."""
+    rng = np.random.default_rng(0)
+    crop = rng.integers(0, 256, (175, 263, 3), dtype=np.uint8)  # partial corner tile: resize + pad path
+    res = nets["m416"](crop, conf=0.25)
+    assert len(res) == 1
+    head_fn = lambda t: ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+    om = opl.OracleModel(nets["n416"], 416, head_fn=head_fn)
+    pts, cls, cf = om.predict_rows(crop, 0.25)
+    assert len(res[0].obb) == len(cls) and len(cls) > 0
+    for k, det in enumerate(res[0].obb):
+        p = [float(v) for v in det.xyxyxyxy[0].flatten().tolist()]
+        assert int(det.cls[0]) == int(cls[k]) and float(det.conf[0]) == float(cf[k])
+        assert max(abs(a - b) for a, b in zip(p, pts[k])) < 2e-3
+    with pytest.raises(ValueError):
+        nets["m416"](np.zeros((10, 10, 4), np.uint8))
+
+
+@pytest.mark.parametrize("H,W,ts,ov,key", [(807, 895, 416, 100, "416"), (300, 500, 128, 30, "128")])
+def test_detect_symbols_vs_oracle_pipeline(ood, nets, H, W, ts, ov, key):
+    """Batched device detect_symbols == the tile-by-tile CPU restatement when both see the same network outputs."""
+    img = np.random.default_rng(7).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    model, net = nets["m" + key], nets["n" + key]
+
+    def head_fn(t):
+        model._ensure_active()
+        return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+    exp = opl.detect_symbols(img, opl.OracleModel(net, ts, head_fn=head_fn), ts, ov)
+    got = ood.detect.detect_symbols(img, model, ts, ov)
+    assert len(exp) > 5
+    _compare_dets(got, exp)
+
+
+def test_process_image_dual_scale_vs_oracle(ood, nets):
+    img = np.random.default_rng(9).integers(0, 256, (500, 640, 3), dtype=np.uint8)
+
+    def hf(model):
+        def f(t):
+            model._ensure_active()
+            return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+        return f
+    oms = [opl.OracleModel(nets["n128"], 128, head_fn=hf(nets["m128"])), opl.OracleModel(nets["n416"], 416, head_fn=hf(nets["m416"]))]
+    exp, exp_by_scale = opl.process_image(img, oms)
+    got = ood.detect.process_image(img, None, [nets["m128"], nets["m416"]])
+    assert sum(len(v) for v in exp_by_scale.values()) > 20
+    _compare_dets(got, exp)
+    cfg = ood.detect.Config(tile_sizes=(416,), overlaps=(100,))
+    got1 = ood.detect.process_image(img, None, [nets["m416"]], cfg)
+    exp1, _ = opl.process_image(img, oms[1:], (416,), (100,))
+    _compare_dets(got1, exp1)

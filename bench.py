@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 416-px tiles/sec of the Detect_OBB.py hot path on MI355X (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch of synthetic 416x416x3 tiles that are already resident in HBM
+(config[1]: YOLOv11n-OBB 3-ch 416x416 tiled inference, single scale):
+    uint8 tiles -> fused preprocess + YOLO11n-OBB forward (MFMA implicit-GEMM convs) -> decode -> ProbIoU Fast-NMS
+    -> result construction -> border filter -> per-tile polygon-IoU merge -> [N>1: RCCL all-gather of survivor records]
+    -> final whole-batch polygon-IoU merge (the fusion step of process_image).
+Nothing is cached or skipped between steps.  With --gpus N every rank processes its own batch (weak scaling) and the
+survivors of all ranks are exchanged every step exactly as the multi-GPU tiler does.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (MFMA, for the conv kernel family: algorithmic FLOPs of
+the forward / HIP-event time of the forward) and "cpu_baseline" (the CPU restatement of the same path, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_TILE = 2 * 1392703312  # YOLO11n-OBB nc=12, 3x416x416
+PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+
+
+def synthetic_rects(B, tile=416, step=316, cols=16):
+    """tile rectangles of a virtual map scanned with the reference's stride (416 - 100)"""
+    r = np.zeros((B, 4), np.int32)
+    for t in range(B):
+        x, y = (t % cols) * step, (t // cols) * step
+        r[t] = (x, y, x + tile, y + tile)
+    return r
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU restatement of the same path (oracle/: torch-CPU fp32 forward, one tile per call like the reference,
+    + oracle post-processing + C geometry), timed on this box's host cores on a bounded sample."""
+    from oracle import pipeline as opl
+    from oracle.yolo11_obb import Yolo11OBB
+    net = Yolo11OBB("n", nc=12, ch=3, seed=0)
+    om = opl.OracleModel(net, 416, "fp32")
+    rng = np.random.default_rng(0)
+    n, t0, dets = 0, time.time(), []
+    while True:
+        crop = rng.integers(0, 256, (416, 416, 3), dtype=np.uint8)
+        img_dets = opl.detect_symbols(crop, om, 416, 100)  # a 416x416 "image" = exactly one full tile
+        dets.extend(img_dets)
+        n += 1
+        if (time.time() - t0 > budget_s and n >= 8) or n >= 512:
+            break
+    from oracle import geom as og
+    og.merge_detections(dets, 0.4)
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 416x416x3 tiles, one model call per tile (reference loop), torch-CPU fp32 + C geometry, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 256)), help="tiles per GPU per step")
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import make_weights
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import detect as D
+    from oriented_object_detection_amd import dist as DD
+    from oriented_object_detection_amd import ops
+    from oriented_object_detection_amd.model import YOLO
+
+    if rank == 0:
+        wpath = make_weights.ensure("n", 12, 3, 0)
+    if world > 1:
+        dist.barrier()
+    wpath = make_weights.path_for("n", 12, 3, 0)
+    model = YOLO(wpath, imgsz=416, precision=args.precision)
+    cfg = D.Config(tile_sizes=(416,), overlaps=(100,))
+    B = args.batch
+    tiles = torch.as_tensor(np.random.default_rng(rank).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).to(dev)
+    rects = synthetic_rects(B * world)
+    rects_dev = torch.as_tensor(rects).to(dev)
+    tile_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
+    fwd_ev = []
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        model._ensure_active()
+        head = ops.forward(tiles)
+        if timed:
+            e1.record()
+            fwd_ev.append((e0, e1))
+        det, cnt = ops.decode_nms(head, 416, 416, cfg.conf_predict, cfg.iou_nms, cfg.max_det)
+        md = cfg.max_det
+        valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
+        rows = torch.nonzero(valid).squeeze(1)
+        if rows.numel():
+            d = det.reshape(-1, 7)[rows].contiguous()
+            slot = (rows // md).long()
+            _, pts = ops.results(d, None)
+            rec = D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), tile_ids[slot].contiguous(), rects_dev, cfg, 416)
+        else:
+            rec = D.TileRecords.empty(dev)
+        if world > 1:
+            rec = DD.all_gather_records(rec)
+        ds = D.records_to_detset(rec, rects_dev, cfg, 416)
+        merged, _ = D.merge_detections_device(ds, cfg.iou_threshold)
+        return len(rec), len(merged)
+
+    for _ in range(args.warmup):
+        nrec, nmerged = step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nrec, nmerged = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev])) if fwd_ev else float("nan")
+
+    if rank == 0:
+        tiles_per_s = world * B * args.steps / dt
+        achieved = B * FLOP_PER_TILE / (fwd_ms * 1e-3) / 1e12
+        out = {
+            "metric": "416px tiles/sec (whole node), YOLOv11n-OBB 3ch",
+            "value": tiles_per_s, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "f16" else "bf16", "data": "synthetic",
+            "config": {"workload": "YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
+                                   "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge",
+                       "tiles_per_gpu_per_step": B, "nc": 12, "weights": "synthetic seeded (no checkpoint offline)",
+                       "survivor_records_per_step": nrec, "final_detections": nmerged},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
+                         "traffic": None, "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

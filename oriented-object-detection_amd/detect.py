@@ -167,60 +167,118 @@ def cross_scale_consensus_filter(dets_by_scale):
 
 
 # ---------------------------------------------------------------- S5
-def _tile_body(local_pts, cls, conf, det_tile, rects_dev, cfg, tile_size):
-    """Per-detection body of the tile loop + per-tile merge, on device.  Inputs are flat over all tiles, in tile order."""
+class TileRecords:
+    """Per-tile survivors in the exchange format of the multi-GPU path (48 B/record):
+    tile index, class, float32 confidence and the 8 float32 LOCAL corners.  Global float64 coordinates and the strike
+    angle are re-derived exactly at the consumer (records_to_detset), so nothing is lost by shipping float32."""
+
+    def __init__(self, tile, cls, conf, pts):
+        self.tile, self.cls, self.conf, self.pts = tile, cls, conf, pts  # i32[n], i32[n], f32[n], f32[n,8]
+
+    def __len__(self):
+        return int(self.tile.shape[0])
+
+    @staticmethod
+    def empty(device):
+        return TileRecords(torch.zeros(0, dtype=torch.int32, device=device), torch.zeros(0, dtype=torch.int32, device=device),
+                           torch.zeros(0, dtype=torch.float32, device=device), torch.zeros((0, 8), dtype=torch.float32, device=device))
+
+    def pack(self):
+        """-> int32 [n,12] (bit-exact container for the all-gather)"""
+        n = len(self)
+        buf = torch.zeros((n, 12), dtype=torch.int32, device=self.tile.device)
+        buf[:, 0], buf[:, 1] = self.tile, self.cls
+        buf[:, 2] = self.conf.contiguous().view(torch.int32)
+        buf[:, 4:] = self.pts.contiguous().view(torch.int32)
+        return buf
+
+    @staticmethod
+    def unpack(buf):
+        return TileRecords(buf[:, 0].contiguous(), buf[:, 1].contiguous(), buf[:, 2].contiguous().view(torch.float32),
+                           buf[:, 4:].contiguous().view(torch.float32))
+
+
+def _tile_records(local_pts, cls, conf32, det_tile, rects_dev, cfg, tile_size):
+    """Per-detection body of the tile loop (:229-262) + per-tile merge (:264) on device; inputs flat over tiles in tile
+    order.  -> TileRecords of the survivors, in the reference's output order."""
     ntiles = rects_dev.shape[0]
+    dev = local_pts.device
     margin = cfg.margin_for(tile_size) if cfg.APPLY_BORDER_FILTER else 0
     gb, ang, ins = ops.tile_postprocess(local_pts, cls, det_tile, rects_dev, margin, cfg.strike_cls)
     sel = torch.nonzero(ins).squeeze(1)
-    gb, ang, cls, conf, det_tile = gb[sel].contiguous(), ang[sel].contiguous(), cls[sel].contiguous(), conf[sel].contiguous(), det_tile[sel]
-    seg = torch.zeros(ntiles + 1, dtype=torch.int32, device=gb.device)
+    if sel.numel() == 0:
+        return TileRecords.empty(dev)
+    gb, cls, conf32, det_tile, local_pts = gb[sel].contiguous(), cls[sel].contiguous(), conf32[sel].contiguous(), det_tile[sel].contiguous(), local_pts[sel]
+    seg = torch.zeros(ntiles + 1, dtype=torch.int32, device=dev)
     seg[1:] = torch.cumsum(torch.bincount(det_tile.long(), minlength=ntiles), 0).int()
-    if gb.shape[0] == 0:
-        return DetSet.empty(gb.device)
-    order, keep = ops.merge_segments(gb, cls, conf, seg, cfg.iou_threshold)
-    kept = order[keep.bool()]
-    return DetSet(gb, cls, conf, ang).select(kept)
+    order, keep = ops.merge_segments(gb, cls, conf32.double(), seg, cfg.iou_threshold)
+    kept = order[keep.bool()].long()
+    return TileRecords(det_tile[kept].contiguous(), cls[kept].contiguous(), conf32[kept].contiguous(), local_pts[kept].contiguous())
 
 
-def detect_symbols_device(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256):
-    """Batched, device-resident detect_symbols for a libobbhip YOLO.  image: uint8 [H,W,C] tensor on the device.
-    -> DetSet in the reference's output order (tile order, confidence order inside a tile)."""
+def records_to_detset(rec, rects_dev, cfg, tile_size):
+    """Rebuild global float64 boxes + strike angles from exchange records (exact: float32 local + integer offset)."""
+    if len(rec) == 0:
+        return DetSet.empty(rec.tile.device)
+    gb, ang, _ = ops.tile_postprocess(rec.pts, rec.cls, rec.tile, rects_dev, 0, cfg.strike_cls)
+    return DetSet(gb, rec.cls, rec.conf.double(), ang)
+
+
+def predict_tile_records(model, tiles, rects_dev, tile_ids, lb, cfg, tile_size, conf):
+    """forward -> decode -> Fast-NMS -> result construction -> border filter -> per-tile merge for one batch of
+    letterboxed tiles.  tile_ids int32[B] (index into rects_dev), lb float[B,3] or None.  -> TileRecords."""
+    dev = tiles.device
+    md = cfg.max_det
+    det, cnt = model.predict_tiles(tiles, conf, cfg.iou_nms, md)
+    valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
+    rows = torch.nonzero(valid).squeeze(1)  # tile-major, score order inside a tile
+    if rows.numel() == 0:
+        return TileRecords.empty(dev)
+    d = det.reshape(-1, 7)[rows].contiguous()
+    slot = (rows // md).long()
+    xywhr, pts = ops.results(d, lb[slot].contiguous() if lb is not None else None)
+    return _tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), tile_ids[slot].contiguous(), rects_dev, cfg, tile_size)
+
+
+def detect_symbols_records(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256, tile_subset=None):
+    """Batched device-resident tile loop for a libobbhip YOLO.  image: uint8 [H,W,C] tensor on the device.
+    tile_subset: optional list of tile indices (the multi-GPU shard).  -> (TileRecords, rects_dev)"""
     H, W, C = image.shape
     conf = cfg.conf_metrics if (conf is None and cfg.calculate_metrics) else (cfg.conf_predict if conf is None else conf)
     rects = ops.tile_grid(H, W, tile_size, overlap)
-    T = len(rects)
-    if T == 0:
-        return DetSet.empty(image.device)
     dev = image.device
-    rects_dev = torch.as_tensor(rects).to(dev)
-    md = cfg.max_det
-    det_all = torch.zeros((T, md, 7), dtype=torch.float32, device=dev)
-    cnt_all = torch.zeros(T, dtype=torch.int32, device=dev)
-    lb_all = torch.zeros((T, 3), dtype=torch.float32, device=dev)
+    rects_dev = torch.as_tensor(rects).to(dev) if len(rects) else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    todo = range(len(rects)) if tile_subset is None else tile_subset
     groups = {}
-    for t, (x, y, x2, y2) in enumerate(rects):
-        groups.setdefault((int(y2 - y), int(x2 - x)), []).append(t)
+    for t in todo:
+        x, y, x2, y2 = rects[t]
+        groups.setdefault((int(y2 - y), int(x2 - x)), []).append(int(t))
+    parts = []
     for (ch, cw), idxs in groups.items():  # one network shape per distinct crop shape (SURVEY Appendix C)
         p = ops.letterbox_shape(ch, cw, model.imgsz)
-        lbv = torch.tensor([p["gain"], p["pad_x"], p["pad_y"]], dtype=torch.float32, device=dev)
         for i0 in range(0, len(idxs), batch):
             part = idxs[i0:i0 + batch]
-            pidx = torch.as_tensor(part, device=dev)
+            pidx = torch.as_tensor(part, dtype=torch.int32, device=dev)
             if ch == cw == model.imgsz:
-                tiles = ops.gather_tiles(image, rects_dev[pidx].contiguous(), model.imgsz)
+                tiles, lb = ops.gather_tiles(image, rects_dev[pidx.long()].contiguous(), model.imgsz), None
             else:
                 tiles = torch.stack([ops.letterbox(image, *[int(v) for v in rects[t]], model.imgsz)[0] for t in part])
-            det, cnt = model.predict_tiles(tiles, conf, cfg.iou_nms, md)
-            det_all[pidx], cnt_all[pidx], lb_all[pidx] = det, cnt, lbv
-    valid = (torch.arange(md, device=dev)[None, :] < cnt_all[:, None]).reshape(-1)
-    rows = torch.nonzero(valid).squeeze(1)  # tile-major, score order inside a tile
-    if rows.numel() == 0:
-        return DetSet.empty(dev)
-    det = det_all.reshape(-1, 7)[rows].contiguous()
-    det_tile = (rows // md).int()
-    xywhr, pts = ops.results(det, lb_all[det_tile.long()].contiguous())
-    return _tile_body(pts, det[:, 5].int().contiguous(), det[:, 4].double().contiguous(), det_tile.contiguous(), rects_dev, cfg, tile_size)
+                lb = torch.tensor([[p["gain"], p["pad_x"], p["pad_y"]]], dtype=torch.float32, device=dev).repeat(len(part), 1)
+            parts.append(predict_tile_records(model, tiles, rects_dev, pidx, lb, cfg, tile_size, conf))
+    if not parts:
+        return TileRecords.empty(dev), rects_dev
+    rec = TileRecords(torch.cat([r.tile for r in parts]), torch.cat([r.cls for r in parts]), torch.cat([r.conf for r in parts]),
+                      torch.cat([r.pts for r in parts]))
+    if len(groups) > 1 and len(rec):  # restore the reference's tile visiting order (stable: keeps score order inside a tile)
+        o = torch.sort(rec.tile, stable=True).indices
+        rec = TileRecords(rec.tile[o].contiguous(), rec.cls[o].contiguous(), rec.conf[o].contiguous(), rec.pts[o].contiguous())
+    return rec, rects_dev
+
+
+def detect_symbols_device(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256):
+    """-> DetSet in the reference's output order (tile order, confidence order inside a tile)."""
+    rec, rects_dev = detect_symbols_records(image, model, tile_size, overlap, cfg, conf, batch)
+    return records_to_detset(rec, rects_dev, cfg, tile_size)
 
 
 def detect_symbols(image, model, tile_size: int, overlap: int, cfg=DEFAULT):
@@ -246,10 +304,11 @@ def detect_symbols(image, model, tile_size: int, overlap: int, cfg=DEFAULT):
     dev = _dev()
     if not pts:
         return []
-    ds = _tile_body(torch.tensor(pts, dtype=torch.float32, device=dev), torch.tensor(cls, dtype=torch.int32, device=dev),
-                    torch.tensor(np.array(cf, np.float32), device=dev).double(), torch.tensor(tid, dtype=torch.int32, device=dev),
-                    torch.as_tensor(rects).to(dev), cfg, tile_size)
-    return ds.to_tuples()
+    rects_dev = torch.as_tensor(rects).to(dev)
+    rec = _tile_records(torch.tensor(pts, dtype=torch.float32, device=dev), torch.tensor(cls, dtype=torch.int32, device=dev),
+                        torch.tensor(np.array(cf, np.float32), device=dev), torch.tensor(tid, dtype=torch.int32, device=dev),
+                        rects_dev, cfg, tile_size)
+    return records_to_detset(rec, rects_dev, cfg, tile_size).to_tuples()
 
 
 def _host(v):

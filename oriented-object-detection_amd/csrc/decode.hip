@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, 
 }
 
 // ---------------------------------------------------------------------------------------------- ProbIoU
-struct RBox { float x, y, A, B, C, det; };  // offset centre + covariance terms (batch_probiou / _get_covariance_matrix)
+struct RBox { float x, y, A, B, C, det, tr; };  // offset centre + covariance terms (batch_probiou / _get_covariance_matrix); tr = A + B
 
 __device__ __forceinline__ RBox make_rbox(float x, float y, float w, float h, float t) {
     RBox r;
@@ -76,6 +76,7 @@ __device__ __forceinline__ RBox make_rbox(float x, float y, float w, float h, fl
     r.C = (a - b) * c * s;
     float dd = r.A * r.B - r.C * r.C;
     r.det = dd > 0.0f ? dd : 0.0f;
+    r.tr = r.A + r.B;
     return r;
 }
 
@@ -93,16 +94,31 @@ __device__ __forceinline__ float probiou(const RBox &p, const RBox &q) {
     return 1.0f - hd;
 }
 
+// Conservative far-apart test.  probiou >= thr  <=>  bd <= BDmax = -log(1 + eps - (1 - thr)^2), and
+// bd >= t1 + t2 = d^T (S1 + S2)^-1 d / 4 >= |d|^2 / (4 trace(S1 + S2))  (t3 >= 0 by AM-GM on the determinants).
+// So |d|^2 > kq * (tr1 + tr2) with kq = 4 * BDmax * 1.05 proves probiou < thr without evaluating it; pairs anywhere near the
+// threshold always take the exact path, so decisions are unchanged.
+__device__ __forceinline__ bool far_apart(const RBox &p, const RBox &q, float kq) {
+    float dx = p.x - q.x, dy = p.y - q.y;
+    return dx * dx + dy * dy > kq * (p.tr + q.tr);
+}
+
+static float far_apart_factor(float thr) {
+    double s = 1.0 + 1e-7 - (1.0 - (double)thr) * (1.0 - (double)thr);
+    if (!(thr > 1e-3f) || s <= 0.0 || s >= 1.0) return INFINITY;  // never reject
+    return (float)(4.0 * -log(s) * 1.05);
+}
+
 // block-wide ordered compaction helper: returns this thread's output slot (or -1) and advances *base by the chunk total
-__device__ __forceinline__ int ordered_slot(bool flag, int *wave_tot /* LDS[4] */, int &base) {
+__device__ __forceinline__ int ordered_slot(bool flag, int *wave_tot /* LDS[16] */, int &base) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
     unsigned long long bal = __ballot(flag);
     int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wave_tot[wave] = __popcll(bal);
     __syncthreads();
     int off = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (k < wave) off += wave_tot[k]; tot += wave_tot[k]; }
+    for (int k = 0; k < nw; ++k) { if (k < wave) off += wave_tot[k]; tot += wave_tot[k]; }
     int slot = flag ? base + off + before : -1;
     base += tot;
     __syncthreads();
@@ -118,24 +134,37 @@ struct NmsScratch {  // per tile, capacity A rows each
     uint8_t *keep;   // sorted order
 };
 
-// One workgroup per tile.
-__global__ __launch_bounds__(256) void k_nms_tile(const float *__restrict__ pred, int A, int nc, float conf_thres, float iou_thres,
-                                                 int max_det, int max_nms, NmsScratch S, float *__restrict__ out,
-                                                 int32_t *__restrict__ count) {
-    __shared__ int wave_tot[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// One workgroup (1024 threads) per tile.  LDS_RESIDENT: every per-candidate array lives in LDS (39 B per anchor,
+// 138 KB for the 3549 anchors of a 416-px tile) so the O(n^2) rank sort and pair loop never leave the CU; tiles with
+// more anchors than fit use the same code on global scratch.
+template <bool LDS_RESIDENT>
+__global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pred, int A, int nc, float conf_thres, float iou_thres,
+                                                  int max_det, int max_nms, float kq, NmsScratch S, float *__restrict__ out,
+                                                  int32_t *__restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    __shared__ int wave_tot[16];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int np = 4 + nc + 1;
     const float *pb = pred + (int64_t)b * A * np;
-    int32_t *cand = S.cand + (int64_t)b * A;
-    float *cscore = S.cscore + (int64_t)b * A;
-    int32_t *ccls = S.ccls + (int64_t)b * A;
-    int32_t *order = S.order + (int64_t)b * A;
-    RBox *rb = S.rb + (int64_t)b * A;
-    uint8_t *keep = S.keep + (int64_t)b * A;
+    RBox *rb; float *cscore; int32_t *cand, *order; uint8_t *ccls, *scls, *keep;
+    if constexpr (LDS_RESIDENT) {
+        char *p = nms_smem;
+        cscore = (float *)p; p += ((size_t)A * 4 + 15) / 16 * 16;
+        rb = (RBox *)p; p += (size_t)A * sizeof(RBox);
+        cand = (int32_t *)p; p += (size_t)A * 4;
+        order = (int32_t *)p; p += (size_t)A * 4;
+        ccls = (uint8_t *)p; p += A;
+        scls = (uint8_t *)p; p += A;
+        keep = (uint8_t *)p;
+    } else {
+        const int64_t AS = (A + 3) & ~3;  // scratch stride per tile (keeps the float4 score reads aligned)
+        rb = S.rb + (int64_t)b * AS; cscore = S.cscore + (int64_t)b * AS; cand = S.cand + (int64_t)b * AS; order = S.order + (int64_t)b * AS;
+        ccls = S.keep + (int64_t)(3 * (int64_t)b) * AS; scls = ccls + AS; keep = scls + AS;
+    }
 
     // 1. candidates in anchor order: conf = max over classes (first maximum), conf > conf_thres
     int n = 0;
-    for (int a0 = 0; a0 < A; a0 += 256) {
+    for (int a0 = 0; a0 < A; a0 += NT) {
         int a = a0 + tid;
         float best = -INFINITY;
         int bj = 0;
@@ -145,46 +174,65 @@ __global__ __launch_bounds__(256) void k_nms_tile(const float *__restrict__ pred
         }
         bool flag = (a < A) && (best > conf_thres);
         int slot = ordered_slot(flag, wave_tot, n);
-        if (flag) { cand[slot] = a; cscore[slot] = best; ccls[slot] = bj; }
+        if (flag) { cand[slot] = a; cscore[slot] = best; ccls[slot] = (uint8_t)bj; }
     }
     __syncthreads();
     if (n == 0) { if (tid == 0) count[b] = 0; return; }
 
     // 2. stable descending rank sort by confidence (torch.argsort(descending=True, stable) restated); n > max_nms keeps the top max_nms
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         float si = cscore[i];
         int rank = 0;
-        for (int j = 0; j < n; ++j) { float sj = cscore[j]; rank += (sj > si) | ((sj == si) & (j < i)); }
+        int n4 = n & ~3;
+        for (int j = 0; j < n4; j += 4) {
+            float4 sj = *reinterpret_cast<const float4 *>(cscore + j);
+            rank += (sj.x > si) | ((sj.x == si) & (j < i));
+            rank += (sj.y > si) | ((sj.y == si) & (j + 1 < i));
+            rank += (sj.z > si) | ((sj.z == si) & (j + 2 < i));
+            rank += (sj.w > si) | ((sj.w == si) & (j + 3 < i));
+        }
+        for (int j = n4; j < n; ++j) { float sj = cscore[j]; rank += (sj > si) | ((sj == si) & (j < i)); }
         order[rank] = i;
     }
     __syncthreads();
     if (n > max_nms) n = max_nms;
-    for (int r = tid; r < n; r += 256) {
+    for (int r = tid; r < n; r += NT) {
         int k = order[r];
         const float *pp = pb + (int64_t)cand[k] * np;
         float c = (float)ccls[k] * kMaxWh;  // class offset: boxes of different classes never overlap
         rb[r] = make_rbox(pp[0] + c, pp[1] + c, pp[2], pp[3], pp[4 + nc]);
+        scls[r] = ccls[k];
     }
     __syncthreads();
 
-    // 3. Fast-NMS: keep r iff no i < r with probiou(i, r) >= thr  (suppressed boxes still suppress)
+    // 3. Fast-NMS: keep r iff no i < r with probiou(i, r) >= thr  (suppressed boxes still suppress).
+    //    One wave per row r, lanes sweep the earlier boxes 64 at a time (coalesced LDS reads, balanced work, early exit per
+    //    row); the class test and the far-apart bound reject almost every pair before the exact ProbIoU.
     const bool skip_other_cls = iou_thres > 1e-3f;  // offset boxes of another class have probiou ~ 0
-    for (int r = tid; r < n; r += 256) {
-        RBox q = rb[r];
-        int cq = ccls[order[r]];
-        bool k = true;
-        for (int i = 0; i < r; ++i) {
-            if (skip_other_cls && ccls[order[i]] != cq) continue;
-            if (probiou(rb[i], q) >= iou_thres) { k = false; break; }
+    {
+        const int lane = tid & 63, wave = tid >> 6, nwave = NT >> 6;
+        for (int r = wave; r < n; r += nwave) {
+            RBox q = rb[r];
+            uint8_t cq = scls[r];
+            bool hit = false;
+            for (int i0 = 0; i0 < r; i0 += 64) {
+                int i = i0 + lane;
+                bool h = false;
+                if (i < r && !(skip_other_cls && scls[i] != cq)) {
+                    RBox p = rb[i];
+                    if (!far_apart(p, q, kq)) h = probiou(p, q) >= iou_thres;
+                }
+                if (__ballot(h)) { hit = true; break; }
+            }
+            if (lane == 0) keep[r] = (uint8_t)!hit;
         }
-        keep[r] = (uint8_t)k;
     }
     __syncthreads();
 
     // 4. first max_det survivors in score order -> rows (x, y, w, h, conf, cls, theta)
     int m = 0;
     float *ob = out + (int64_t)b * max_det * 7;
-    for (int r0 = 0; r0 < n && m < max_det; r0 += 256) {
+    for (int r0 = 0; r0 < n && m < max_det; r0 += NT) {
         int r = r0 + tid;
         bool flag = (r < n) && keep[r];
         int slot = ordered_slot(flag, wave_tot, m);
@@ -317,13 +365,13 @@ __global__ __launch_bounds__(256) void k_letterbox(const uint8_t *__restrict__ i
 }
 
 static int nms_scratch(obb_ctx *ctx, int B, int A, NmsScratch &S) {
-    size_t rows = (size_t)B * A;
+    size_t rows = (size_t)B * ((A + 3) & ~3);
     S.cand = (int32_t *)ctx->workspace(WS_NMS_A, rows * 4);
     S.cscore = (float *)ctx->workspace(WS_NMS_B, rows * 4);
     S.ccls = (int32_t *)ctx->workspace(WS_NMS_C, rows * 4);
     S.order = (int32_t *)ctx->workspace(WS_NMS_D, rows * 4);
     S.rb = (RBox *)ctx->workspace(WS_GEOM_A, rows * sizeof(RBox));
-    S.keep = (uint8_t *)ctx->workspace(WS_GEOM_B, rows);
+    S.keep = (uint8_t *)ctx->workspace(WS_GEOM_B, rows * 3);
     if (!S.cand || !S.cscore || !S.ccls || !S.order || !S.rb || !S.keep) return set_error(ctx, OBB_ERR_HIP, "NMS workspace allocation failed");
     return OBB_OK;
 }
@@ -362,8 +410,20 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
     hipStream_t st = (hipStream_t)s;
     hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, st, head, B, A, nc, h, w, pred);
     OBB_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_nms_tile, dim3((unsigned)B), dim3(256), 0, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det, 30000, S, out,
-                       count);
+    OBB_REQUIRE(ctx, nc <= 255, "obb_decode_nms: nc > 255 unsupported");
+    size_t lds = (size_t)A * (sizeof(RBox) + 12 + 3) + 96;
+    if (lds <= 159 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            OBB_HIP(ctx, hipFuncSetAttribute((const void *)k_nms_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_nms_tile<true>, dim3((unsigned)B), dim3(1024), lds, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
+                           30000, far_apart_factor(iou_thres), S, out, count);
+    } else {
+        hipLaunchKernelGGL(k_nms_tile<false>, dim3((unsigned)B), dim3(1024), 0, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
+                           30000, far_apart_factor(iou_thres), S, out, count);
+    }
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

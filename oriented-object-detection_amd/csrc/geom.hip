@@ -9,6 +9,8 @@
 //
 // All of this is byte/compare work on KB..MB inputs: the kernels are HBM/latency bound, so the design rules are
 // coalesced SoA streams, LDS-resident segments, wave64 ballots/shuffles for the serial scans, and no GEMM shaping.
+#include <algorithm>
+
 #include "ctx.h"
 #include "geom_device.h"
 
@@ -122,9 +124,13 @@ __device__ __forceinline__ bool meta_overlap(const BoxMeta &a, const BoxMeta &b)
 // class+envelope tests of its row.  Phase 2: the surviving pairs are compacted through LDS and clipped one per lane.
 // Output word layout is column-block-major: word (row i, block jb) lives at mask[jb * n + i] so that both this
 // kernel's stores and the scan kernel's loads are 512 B contiguous per wave.
+// EDGES: instead of the dense matrix, append one (i, j) record per suppression pair to an edge list (sparse form used by
+// obb_merge_detections; the pair set is tiny compared with n^2 / 64 words).
+template <bool EDGES>
 __global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sboxes, const int32_t *__restrict__ scls,
                                                 const BoxMeta *__restrict__ meta, int64_t n, double thr,
-                                                unsigned long long *__restrict__ mask) {
+                                                unsigned long long *__restrict__ mask, unsigned long long *__restrict__ edges,
+                                                unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
     int jb = blockIdx.x, ib = blockIdx.y;
     if (jb < ib) return;
     __shared__ BoxMeta cm[64];
@@ -173,11 +179,84 @@ __global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sbox
             P2 p[4], q[4];
             for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
             double iou = poly_iou_core(p, q);
-            if (iou >= thr) atomicOr(&bits[r], 1ull << c);
+            if (iou >= thr) {
+                if constexpr (EDGES) {
+                    unsigned int e = atomicAdd(edge_count, 1u);
+                    if (e < edge_cap) edges[e] = ((unsigned long long)((int64_t)ib * 64 + r) << 32) | (unsigned long long)((int64_t)jb * 64 + c);
+                } else atomicOr(&bits[r], 1ull << c);
+            }
         }
     }
+    if constexpr (EDGES) {
+        unsigned long long dw = direct;  // thr <= 0: every same-class pair is an edge
+        while (dw) {
+            int c = __ffsll((long long)dw) - 1;
+            dw &= dw - 1;
+            unsigned int e = atomicAdd(edge_count, 1u);
+            if (e < edge_cap) edges[e] = ((unsigned long long)i << 32) | (unsigned long long)((int64_t)jb * 64 + c);
+        }
+    } else {
+        __syncthreads();
+        if (i < n) mask[(int64_t)jb * n + i] = bits[lane] | direct;
+    }
+}
+
+// Greedy resolution on the sparse suppression graph (edges i -> j, i < j in confidence order):
+//   keep[j] <=> every predecessor of j is dropped;  drop[j] <=> some predecessor is kept.
+// The graph is a DAG ordered by index, so relaxing all undecided nodes in parallel reaches the greedy fixed point of
+// Detect_OBB.py:186-198 in (longest suppression chain) rounds.  Single workgroup; node states live in LDS, 1 byte each:
+// bits 0-1 = state (0 undecided, 1 keep, 2 drop), bit 2 = "a kept predecessor seen", bit 3 = "an undecided predecessor seen".
+__global__ __launch_bounds__(1024) void k_nms_resolve(const unsigned long long *__restrict__ edges, const unsigned int *__restrict__ edge_count,
+                                                     int64_t n, uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep) {
+    extern __shared__ unsigned int st_words[];  // ceil(n/4) words
+    __shared__ int undecided_s, total_s;
+    const int tid = threadIdx.x;
+    const int nw = (int)((n + 3) / 4);
+    const unsigned int E = *edge_count;
+    for (int w = tid; w < nw; w += 1024) st_words[w] = 0u;
+    if (tid == 0) total_s = 0;
     __syncthreads();
-    if (i < n) mask[(int64_t)jb * n + i] = bits[lane] | direct;
+    for (int round = 0; round <= n; ++round) {
+        if (tid == 0) undecided_s = 0;
+        for (unsigned int e = tid; e < E; e += 1024) {
+            unsigned long long ed = edges[e];
+            unsigned int i = (unsigned int)(ed >> 32), j = (unsigned int)ed;
+            unsigned int sj = (st_words[j >> 2] >> ((j & 3) * 8)) & 3u;
+            if (sj != 0u) continue;
+            unsigned int si = (st_words[i >> 2] >> ((i & 3) * 8)) & 3u;
+            if (si == 1u) atomicOr(&st_words[j >> 2], 4u << ((j & 3) * 8));
+            else if (si == 0u) atomicOr(&st_words[j >> 2], 8u << ((j & 3) * 8));
+        }
+        __syncthreads();
+        int local_und = 0;
+        for (int w = tid; w < nw; w += 1024) {
+            unsigned int v = st_words[w], o = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned int s = (v >> (k * 8)) & 0xffu;
+                if ((s & 3u) == 0u) {
+                    if (s & 4u) s = 2u;
+                    else if (!(s & 8u)) s = 1u;
+                    else { s = 0u; if ((int64_t)w * 4 + k < n) local_und = 1; }
+                }
+                o |= s << (k * 8);
+            }
+            st_words[w] = o;
+        }
+        if (local_und) undecided_s = 1;  // benign race: all writers store 1
+        __syncthreads();
+        if (!undecided_s) break;
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int64_t i = tid; i < n; i += 1024) {
+        unsigned int s = (st_words[i >> 2] >> ((i & 3) * 8)) & 3u;
+        keep[i] = (uint8_t)(s == 1u);
+        cnt += (s == 1u);
+    }
+    atomicAdd(&total_s, cnt);
+    __syncthreads();
+    if (tid == 0 && n_keep) *n_keep = total_s;
 }
 
 // Greedy scan (single workgroup, 1024 threads = 16 waves).  Chunk rb of 64 rows: wave 0 resolves the diagonal block
@@ -224,27 +303,35 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const unsigned long long *_
 static constexpr int kSegMax = 512;
 static constexpr int kSegWords = kSegMax / 64;
 
-// One workgroup per segment: rank sort, pair tests, greedy scan -- everything in LDS.
-__global__ __launch_bounds__(256) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
-                                                       const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
-                                                       double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
-                                                       int32_t *__restrict__ n_keep, int32_t *__restrict__ status) {
+// One workgroup (1024 threads) per segment: rank sort, pair tests, greedy scan -- everything in LDS.
+// The cheap class + envelope tests emit a compact candidate-pair list; the expensive fp64 clipping is then spread evenly
+// over all lanes (a row-per-thread loop would leave most of the group idle behind the few crowded rows).
+static constexpr int kSegPairCap = 12288;
+
+__global__ __launch_bounds__(1024) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                        const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
+                                                        double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
+                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status) {
     __shared__ double skey[kSegMax];
     __shared__ int32_t sord[kSegMax];
     __shared__ int32_t scl[kSegMax];
     __shared__ BoxMeta smeta[kSegMax];
     __shared__ unsigned long long sbits[kSegMax * kSegWords];
+    __shared__ unsigned int spairs[kSegPairCap];
+    __shared__ unsigned int npairs_s;
+    const int NT = 1024;
     int seg = blockIdx.x;
     int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
     int n = s1 - s0;
     if (n <= 0) { if (threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }
-    if (n > kSegMax) {  // caller promised max_seg_len <= kSegMax; flag and leave outputs untouched
+    if (n > kSegMax) {  // caller promised segments <= kSegMax; flag and leave outputs untouched
         if (threadIdx.x == 0) atomicExch(status, 1);
         return;
     }
-    for (int t = threadIdx.x; t < n; t += 256) skey[t] = sort_key(conf[s0 + t]);
+    if (threadIdx.x == 0) npairs_s = 0;
+    for (int t = threadIdx.x; t < n; t += NT) skey[t] = sort_key(conf[s0 + t]);
     __syncthreads();
-    for (int t = threadIdx.x; t < n; t += 256) {
+    for (int t = threadIdx.x; t < n; t += NT) {
         double ki = skey[t];
         int rank = 0;
         for (int u = 0; u < n; ++u) rank += (skey[u] > ki) | ((skey[u] == ki) & (u < t));
@@ -252,7 +339,7 @@ __global__ __launch_bounds__(256) void k_merge_segments(const double *__restrict
     }
     __syncthreads();
     int W = (n + 63) / 64;
-    for (int t = threadIdx.x; t < n; t += 256) {
+    for (int t = threadIdx.x; t < n; t += NT) {
         int src = s0 + sord[t];
         order[s0 + t] = src;
         P2 p[4];
@@ -265,26 +352,46 @@ __global__ __launch_bounds__(256) void k_merge_segments(const double *__restrict
         for (int w = 0; w < W; ++w) sbits[t * kSegWords + w] = 0ull;
     }
     __syncthreads();
-    bool all_hit = !(thr > 0.0);
-    // pair (i, j>i): flatten rows over threads; rows are short so a strided row loop balances well enough
-    for (int i = threadIdx.x; i < n; i += 256) {
-        BoxMeta rm = smeta[i];
-        int rc = scl[i];
-        const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8;
-        P2 p[4];
-        bool loaded = false;
-        for (int j = i + 1; j < n; ++j) {
-            if (scl[j] != rc) continue;
-            bool hit = all_hit;
-            if (!all_hit && meta_overlap(rm, smeta[j])) {
-                if (!loaded) { for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; } loaded = true; }
-                const double *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
-                P2 q[4];
-                for (int k = 0; k < 4; ++k) { q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
-                hit = poly_iou_core(p, q) >= thr;
+    const bool all_hit = !(thr > 0.0);
+    // phase A: cheap tests over the strict upper triangle, flattened so that every lane gets the same number of pairs
+    const int npair_total = n * (n - 1) / 2;
+    for (int base = 0; base < npair_total; base += NT) {
+        int pidx = base + threadIdx.x;
+        bool cand = false;
+        int i = 0, j = 0;
+        if (pidx < npair_total) {
+            // row i of the triangle: first index f(i) = i*(2n-i-1)/2 ; invert with a float guess + fix-up
+            float fn = (float)n - 0.5f;
+            i = (int)(fn - sqrtf(fn * fn - 2.0f * (float)pidx));
+            if (i < 0) i = 0;
+            while (i > 0 && i * (2 * n - i - 1) / 2 > pidx) --i;
+            while ((i + 1) * (2 * n - i - 2) / 2 <= pidx) ++i;
+            j = pidx - i * (2 * n - i - 1) / 2 + i + 1;
+            if (scl[i] == scl[j]) {
+                if (all_hit) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
+                else cand = meta_overlap(smeta[i], smeta[j]);
             }
-            if (hit) sbits[i * kSegWords + (j >> 6)] |= 1ull << (j & 63);
         }
+        if (cand) {
+            unsigned int slot = atomicAdd(&npairs_s, 1u);
+            if (slot < (unsigned)kSegPairCap) spairs[slot] = ((unsigned)i << 16) | (unsigned)j;
+            else {  // list full (pathologically crowded tile): clip right here
+                P2 p[4], q[4];
+                const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8, *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
+                for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
+                if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
+            }
+        }
+    }
+    __syncthreads();
+    // phase B: exact fp64 clipping, one candidate pair per lane
+    int npairs = (int)min(npairs_s, (unsigned)kSegPairCap);
+    for (int t = threadIdx.x; t < npairs; t += NT) {
+        int i = spairs[t] >> 16, j = spairs[t] & 0xffff;
+        P2 p[4], q[4];
+        const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8, *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
+        for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
+        if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // wave 0: lane w owns word w of `removed`
@@ -458,8 +565,8 @@ static int nms_mask_impl(obb_ctx *ctx, const double *sboxes, const int32_t *scls
                          uint64_t *mask, hipStream_t st) {
     int64_t W = cdiv(n, 64);
     OBB_REQUIRE(ctx, W <= 65535, "nms: n=%lld exceeds the 4.19M-box grid limit", (long long)n);
-    hipLaunchKernelGGL(k_nms_mask, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, sboxes, scls, meta, n, thr,
-                       (unsigned long long *)mask);
+    hipLaunchKernelGGL(k_nms_mask<false>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, sboxes, scls, meta, n, thr,
+                       (unsigned long long *)mask, (unsigned long long *)nullptr, (unsigned int *)nullptr, 0u);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }
@@ -499,7 +606,7 @@ int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, co
     int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
     if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
     OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), (hipStream_t)s));
-    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(256), 0, (hipStream_t)s, boxes, cls, conf, seg_off, thr,
+    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, (hipStream_t)s, boxes, cls, conf, seg_off, thr,
                        order, keep, (int32_t *)nullptr, status);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
@@ -521,21 +628,49 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         int32_t h[2] = {0, (int32_t)n};
         OBB_HIP(ctx, hipMemcpyAsync(segoff, h, sizeof h, hipMemcpyHostToDevice, st));
         OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(256), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status);
+        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }
     int64_t W = cdiv(n, 64);
+    OBB_REQUIRE(ctx, W <= 65535, "nms: n=%lld exceeds the 4.19M-box grid limit", (long long)n);
     double *sboxes = (double *)ctx->workspace(WS_GEOM_A, sizeof(double) * 8 * (size_t)n);
     int32_t *scls = (int32_t *)ctx->workspace(WS_GEOM_B, sizeof(int32_t) * (size_t)n);
     BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)n);
-    uint64_t *mask = (uint64_t *)ctx->workspace(WS_NMS_B, sizeof(uint64_t) * (size_t)(W * n));
-    if (!sboxes || !scls || !meta || !mask) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+    if (!sboxes || !scls || !meta) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
     int rc = obb_sort_desc_stable(ctx, conf, n, order, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_prep_sorted, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, boxes, cls, (const int32_t *)order, n, sboxes,
                        scls, meta);
     OBB_LAUNCH_CHECK(ctx);
+    // sparse form: suppression pairs as an edge list + parallel DAG relaxation (node states in LDS: n <= 600k)
+    const size_t lds_states = (size_t)cdiv(n, 4) * 4;
+    if (thr > 0.0 && lds_states <= 150 * 1024) {
+        const unsigned int cap = (unsigned int)std::min<int64_t>(64 * n + 4096, 1ll << 28);
+        unsigned long long *edges = (unsigned long long *)ctx->workspace(WS_NMS_C, sizeof(unsigned long long) * (size_t)cap);
+        unsigned int *ecount = (unsigned int *)ctx->workspace(WS_NMS_D, 256);
+        if (!edges || !ecount) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+        OBB_HIP(ctx, hipMemsetAsync(ecount, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,
+                           (const BoxMeta *)meta, n, thr, (unsigned long long *)nullptr, edges, ecount, cap);
+        OBB_LAUNCH_CHECK(ctx);
+        unsigned int E = 0;
+        OBB_HIP(ctx, hipMemcpyAsync(&E, ecount, sizeof E, hipMemcpyDeviceToHost, st));
+        OBB_HIP(ctx, hipStreamSynchronize(st));  // the pair count decides between the sparse and the dense scan
+        if (E <= cap) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                OBB_HIP(ctx, hipFuncSetAttribute((const void *)k_nms_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_nms_resolve, dim3(1), dim3(1024), lds_states, st, (const unsigned long long *)edges, (const unsigned int *)ecount, n,
+                               keep, n_keep);
+            OBB_LAUNCH_CHECK(ctx);
+            return OBB_OK;
+        }
+    }
+    uint64_t *mask = (uint64_t *)ctx->workspace(WS_NMS_B, sizeof(uint64_t) * (size_t)(W * n));
+    if (!mask) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
     rc = nms_mask_impl(ctx, sboxes, scls, meta, n, thr, mask, st);
     if (rc) return rc;
     return obb_nms_reduce(ctx, mask, n, keep, n_keep, s);

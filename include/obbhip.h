@@ -111,9 +111,13 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes);
 /* nc, input channels, number of anchors A for an (h, w) input, number of weight records. */
 int obb_model_info(const obb_ctx *ctx, int32_t h, int32_t w, int32_t *nc, int32_t *ch, int32_t *anchors, int32_t *nconv);
 /* OBBModel forward on B letterboxed inputs: tiles uint8[B*h*w*ch] (NHWC; BGR for ch==3 exactly as the reference
- * passes crops, Detect_OBB.py:93) -> raw head float[B*A*(64+nc+1)] (per anchor: 4x16 DFL logits, nc class logits,
- * 1 angle logit).  Preprocess (BGR->RGB, /255; Appendix A2) is fused into the first convolution. */
+ * passes crops, Detect_OBB.py:93) -> raw head float[B*A*NO] with NO = 64+nc+1 rounded up to a multiple of 4 (per anchor:
+ * 4x16 DFL logits, nc class logits, 1 angle logit, zero padding).  Preprocess (BGR->RGB, /255; Appendix A2) is fused
+ * into the first convolution. */
 int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s);
+/* Debug: text dump of the lowered forward for an (h, w) input -- one line per kernel launch (layer name, tiling,
+ * grid, LDS bytes, MACs).  buf_host may be NULL to query *needed. */
+int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf_host, int64_t buf_bytes, int64_t *needed);
 /* Debug/parity tap: copy the activation called `name` (a conv's state-dict path such as "model.2.cv1", or a
  * layer output "x0".."x22") of the last forward to out as dense float[B*H*W*C] (bf16 widened).  out may be NULL to
  * query *n_elems / shape only. */

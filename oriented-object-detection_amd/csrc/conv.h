@@ -33,6 +33,7 @@ struct ConvLaunch {
     int act = 1;
     int in_u8 = 0, out_f32 = 0, flip_bgr = 0;
     int f16 = 1;  // storage type: 1 = fp16, 0 = bf16
+    int out_hw = 0;  // > 0: 1-D launch whose OUTPUT is split per image: pixel P -> (b = P / out_hw, P % out_hw) with out.bs
     // tiling (chosen by plan_conv)
     int TH = 1, TW = 64, MF = 1, NF = 4, CK = 32;
     int tiles_y = 1, tiles_x = 1;

@@ -31,7 +31,7 @@ struct ConvParams {
     const bf16_t *res; int64_t res_bs; int res_cs, res_co;
     const bf16_t *wpk; const float *bias; const bf16_t *lut;
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
-    int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst;
+    int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw;
     float inv_twin, inv_tw;
 };
 
@@ -77,8 +77,48 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    __shared__ __attribute__((aligned(16))) bf16_t s_lut[IN_U8 ? 256 : 8];  // sized in multiples of 16 B: statics precede the dynamic LDS region  // u8 -> half(v/255) table of the network input layer
+    if constexpr (IN_U8) s_lut[tid] = P.lut[tid];
+
     const int nq = (KS == 3 ? 9 : 1) * cpk;
     const int in_px = THin * TWin;
+
+    // Staging plan of this thread (16-B chunks idx = tid + k*256 of the [in_px][CK] tile): the pixel -> global offset map is
+    // the same for every channel stage, so it is computed once; stage s only adds s*CK channels.
+    constexpr int MAXLD = 8;
+    int64_t goff[MAXLD];  // element offset of the chunk at stage 0, or -1 when the pixel is outside the image (zero padding)
+    const int nchunk = in_px << P.sh;
+    if constexpr (!IN_U8) {
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            int idx = tid + k * 256;
+            int pix = idx >> P.sh, c8 = idx & (cpk - 1);
+            int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
+            int ix = pix - iy * TWin;
+            int gy = iy0 + iy, gx = ix0 + ix;
+            bool ok = idx < nchunk && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+            goff[k] = ok ? ((int64_t)gy * P.Win + gx) * P.in_cs + c8 * 8 : -1;
+        }
+    }
+    const bf16_t *src0 = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co;
+    uint4 pre[MAXLD];
+    auto load_stage = [&](int stage) {  // global -> registers (asynchronous until the values are used)
+        const int crem = P.cin - stage * P.CK;  // channels left (multiple of 8): the last stage may be partial
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            int c8 = (tid + k * 256) & (cpk - 1);
+            pre[k] = make_uint4(0, 0, 0, 0);
+            if (goff[k] >= 0 && c8 * 8 < crem) pre[k] = *reinterpret_cast<const uint4 *>(src0 + goff[k] + stage * P.CK);
+        }
+    };
+    auto store_stage = [&]() {  // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            int idx = tid + k * 256;
+            if (idx < nchunk) *reinterpret_cast<uint4 *>(smem + (idx >> P.sh) * PST + (idx & (cpk - 1)) * 16) = pre[k];
+        }
+    };
+    if constexpr (!IN_U8) load_stage(0);
 
     for (int stage = 0; stage < P.nstage; ++stage) {
         __syncthreads();
@@ -92,29 +132,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
                     const uint8_t *s = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
-                    uint32_t c0 = P.lut[s[P.flip_bgr ? 2 : 0]], c1 = P.lut[s[1]], c2 = P.lut[s[P.flip_bgr ? 0 : 2]];
-                    uint32_t c3 = (P.cin == 4) ? (uint32_t)P.lut[s[3]] : 0u;
+                    uint32_t c0 = s_lut[s[P.flip_bgr ? 2 : 0]], c1 = s_lut[s[1]], c2 = s_lut[s[P.flip_bgr ? 0 : 2]];
+                    uint32_t c3 = (P.cin == 4) ? (uint32_t)s_lut[s[3]] : 0u;
                     v.x = c0 | (c1 << 16);
                     v.y = c2 | (c3 << 16);
                 }
                 *reinterpret_cast<uint4 *>(smem + pix * PST) = v;
             }
+            __syncthreads();
         } else {
-            const bf16_t *src = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co + stage * P.CK;
-            const int nchunk = in_px << P.sh;
-            const int crem = P.cin - stage * P.CK;  // channels left in this stage (multiple of 8)
-            for (int idx = tid; idx < nchunk; idx += 256) {
-                int pix = idx >> P.sh, c8 = idx & (cpk - 1);
-                int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
-                int ix = pix - iy * TWin;
-                int gy = iy0 + iy, gx = ix0 + ix;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win && c8 * 8 < crem)
-                    v = *reinterpret_cast<const uint4 *>(src + ((int64_t)gy * P.Win + gx) * P.in_cs + c8 * 8);
-                *reinterpret_cast<uint4 *>(smem + pix * PST + c8 * 16) = v;
-            }
+            store_stage();
+            __syncthreads();
+            // prefetch the next channel stage into registers: its HBM/L2 latency hides under this stage's MFMAs
+            if (stage + 1 < P.nstage) load_stage(stage + 1);
         }
-        __syncthreads();
 
         // ---- K loop over this stage: weights from global (fragment order), activations from LDS
         const bf16x8 *wst = reinterpret_cast<const bf16x8 *>(P.wpk) + ((int64_t)(cb * P.nstage + stage) * P.kst) * NF * 64 + lane;
@@ -194,10 +225,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
             }
         }
         if constexpr (OUT_F32) {
-            float *op = (float *)P.out + (int64_t)b * P.out_bs + (int64_t)opix[mf] * P.out_cs + P.out_co + cbase;
+            int64_t ob = b, opx = opix[mf];
+            if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }  // 1-D launch, per-image output rows (network head)
+            float *op = (float *)P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
+            if (full && ((P.out_cs | P.out_co) & 3) == 0) {
 #pragma unroll
-            for (int c = 0; c < NF * 4; ++c)
-                if (cbase + c < P.cout) op[c] = v[c];
+                for (int f = 0; f < NF; ++f) *reinterpret_cast<float4 *>(op + f * 4) = make_float4(v[f * 4], v[f * 4 + 1], v[f * 4 + 2], v[f * 4 + 3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NF * 4; ++c)
+                    if (cbase + c < P.cout) op[c] = v[c];
+            }
         } else {
             bf16_t *op = (bf16_t *)P.out + (int64_t)b * P.out_bs + (int64_t)opix[mf] * P.out_cs + P.out_co + cbase;
             if (full) {
@@ -319,7 +357,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout;
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2(L.CK / 8);
-    P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y;
+    P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw;
     int cin_eff = L.in_u8 ? 8 : L.cin;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;
     P.kst = conv_ksteps(L.ks, L.CK);
@@ -327,6 +365,10 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
     if ((1 << P.sh) != L.CK / 8 || L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
+    {
+        int THin = (L.TH - 1) * L.stride + L.ks;
+        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > 8 * 256) return hipErrorInvalidValue;  // staging plan holds 8 chunks per thread
+    }
     int ncb = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
     dim3 grid((unsigned)((int64_t)L.B * L.tiles_y * L.tiles_x), (unsigned)ncb);
     size_t lds = conv_lds_bytes(L);

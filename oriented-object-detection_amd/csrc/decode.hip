@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, 
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)B * A) return;
     int a = (int)(i % A);
-    const int no = 4 * kRegMaxD + nc + 1, np = 4 + nc + 1;
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4, np = 4 + nc + 1;  // head rows are padded to a multiple of 4 floats
     const float *hp = head + i * no;
     // anchor of this row: levels P3, P4, P5 concatenated, row-major inside a level, centres at +0.5
     int n8 = (h / 8) * (w / 8), n16 = (h / 16) * (w / 16);

@@ -51,7 +51,7 @@ struct Op {
 };
 
 struct Plan {
-    int h = 0, w = 0, A = 0, no = 0;
+    int h = 0, w = 0, A = 0, no = 0, no_pad = 0;
     std::vector<Buf> bufs;
     std::vector<Op> ops;
     std::map<std::string, Slice> named;
@@ -178,9 +178,8 @@ struct Builder {
         op.H = Hin; op.W = Win;
         op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
-        op.one_d = (r->k == 1 && head_level < 0);
-        ConvTiling t = plan_conv(op.one_d ? 1 : (r->k == 1 ? 3 /*2D tiling rules*/ : r->k), r->s, cin, r->c2, op.Ho, op.Wo);
-        if (r->k == 1 && !op.one_d) t.CK = cin >= 64 ? 64 : 32;
+        op.one_d = (r->k == 1);
+        ConvTiling t = plan_conv(r->k, r->s, cin, r->c2, op.Ho, op.Wo);
         if (in_u8) t.CK = 8;
         ConvLaunch &L = op.conv;
         L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act;
@@ -347,6 +346,7 @@ struct Builder {
         const int Hs[3] = {H8, H16, H32}, Ws[3] = {W8, W16, W32};
         int c2 = std::max(std::max(16, chs[0] / 4), kRegMax * 4), c3 = std::max(chs[0], std::min(M.nc, 100)), c4 = std::max(chs[0] / 4, 1);
         P.no = 4 * kRegMax + M.nc + 1;
+        P.no_pad = (P.no + 3) / 4 * 4;  // head rows padded to 16 B so that every lane stores whole float4s
         int off = 0;
         for (int i = 0; i < 3; ++i) { P.lvl_off[i] = off; off += Hs[i] * Ws[i]; }
         P.A = off;
@@ -440,8 +440,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
                 } else L.in = tref(P, op.in);
                 if (op.head_level >= 0) {
-                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no;
-                    L.out.bs = (int64_t)P.A * P.no; L.out.cs = P.no; L.out.co = op.out.co;
+                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
+                    if (op.one_d) L.out_hw = op.Ho * op.Wo;
                 } else L.out = tref(P, op.out);
                 L.res = tref(P, op.res);
                 if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
@@ -542,6 +543,46 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     rc = ensure_capacity(ctx, *P, B);
     if (rc) return rc;
     return run_forward(ctx, *P, tiles, B, head, (hipStream_t)s);
+}
+
+int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_bytes, int64_t *needed) {
+    OBB_REQUIRE(ctx, ctx && needed, "obb_debug_plan: bad arguments");
+    Plan *P = nullptr;
+    int rc = get_plan(ctx, h, w, &P);
+    if (rc) return rc;
+    std::string out;
+    char line[512];
+    for (const Op &op : P->ops) {
+        double macs = 0;
+        const char *ty = "?";
+        int grid_x = 0, grid_y = 0, lds = 0;
+        switch (op.type) {
+            case OP_CONV: {
+                ty = "conv";
+                const ConvLaunch &L = op.conv;
+                macs = (double)op.Ho * op.Wo * L.cout * L.cin * L.ks * L.ks;
+                grid_x = op.one_d ? -(op.Ho * op.Wo) : L.tiles_x * L.tiles_y;  // negative: pixels per image of a 1-D launch
+                grid_y = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
+                lds = (int)conv_lds_bytes(L);
+                snprintf(line, sizeof line, "%s %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d MF%d NF%d CK%d gx%d gy%d lds%d macs%.0f\n", ty,
+                         op.name.c_str(), L.ks, L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.MF, L.NF, L.CK, grid_x, grid_y, lds, macs);
+                break;
+            }
+            case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
+                snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
+            case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_ATTN: macs = (double)op.nh * ((double)op.N * op.N * op.kd + (double)op.N * op.N * op.hd);
+                snprintf(line, sizeof line, "attn %s N%d nh%d macs%.0f\n", op.name.c_str(), op.N, op.nh, macs); break;
+        }
+        out += line;
+    }
+    snprintf(line, sizeof line, "total_macs %.0f bytes_per_img %lld nbufs %zu nops %zu\n", P->macs_per_img, (long long)P->bytes_per_img, P->bufs.size(),
+             P->ops.size());
+    out += line;
+    *needed = (int64_t)out.size() + 1;
+    if (buf && buf_bytes >= *needed) memcpy(buf, out.c_str(), out.size() + 1);
+    return OBB_OK;
 }
 
 int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const char *name, float *out, int64_t max_elems,

@@ -196,9 +196,30 @@ def forward(tiles):
     info = model_info(h, w, t.device)
     if ch != info["ch"]:
         raise ValueError(f"forward: model expects {info['ch']} input channels, got {ch}")
-    head = torch.empty((B, info["anchors"], 64 + info["nc"] + 1), dtype=torch.float32, device=t.device)
+    no = 64 + info["nc"] + 1
+    head = torch.zeros((B, info["anchors"], (no + 3) // 4 * 4), dtype=torch.float32, device=t.device)
     _call("obb_forward", ctx(t.device), _p(t), B, h, w, _p(head), _stream())
-    return head
+    return head  # rows padded to a multiple of 4 floats; [..., :64+nc+1] are the logits
+
+
+def _padded_head(hd):
+    """accept unpadded [B,A,64+nc+1] heads (e.g. from the oracle) by padding rows to the device layout"""
+    no = hd.shape[-1]
+    if no % 4 == 0:
+        return hd
+    out = torch.zeros(hd.shape[:-1] + ((no + 3) // 4 * 4,), dtype=hd.dtype, device=hd.device)
+    out[..., :no] = hd
+    return out
+
+
+def debug_plan(h, w, device=None):
+    """-> list of text lines, one per kernel launch of the lowered forward (layer, tiling, grid, LDS, MACs)"""
+    c = ctx(device)
+    need = C.c_int64(0)
+    _call("obb_debug_plan", c, h, w, None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value)
+    _call("obb_debug_plan", c, h, w, buf, need.value, C.byref(need))
+    return buf.value.decode().strip().split("\n")
 
 
 def debug_activation(name, B, h, w, device=None):
@@ -213,16 +234,16 @@ def debug_activation(name, B, h, w, device=None):
 
 def decode(head, h, w):
     """raw head [B,A,64+nc+1] -> predictions [B,A,4+nc+1] (x,y,w,h, class scores, theta); anchor-major."""
-    hd = _chk(head, torch.float32, "head")
-    B, A, no = hd.shape
-    pred = torch.empty((B, A, no - 64 + 4), dtype=torch.float32, device=hd.device)
+    hd = _padded_head(_chk(head, torch.float32, "head"))
+    B, A, _ = hd.shape
+    pred = torch.empty((B, A, 4 + model_info(h, w, hd.device)["nc"] + 1), dtype=torch.float32, device=hd.device)
     _call("obb_decode", ctx(hd.device), _p(hd), B, h, w, _p(pred), _stream())
     return pred
 
 
 def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300):
     """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B])"""
-    hd = _chk(head, torch.float32, "head")
+    hd = _padded_head(_chk(head, torch.float32, "head"))
     B = hd.shape[0]
     det = torch.zeros((B, max_det, 7), dtype=torch.float32, device=hd.device)
     count = torch.zeros(B, dtype=torch.int32, device=hd.device)

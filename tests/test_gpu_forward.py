@@ -72,7 +72,7 @@ def test_layer_taps_match_bf16_oracle(ops, net_n):
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 1), (192, 416, 2)])
 def test_head_matches_oracles(ops, net_n, h, w, B):
     x = _tiles(10 + h + w, B, h, w)
-    head = ops.forward(torch.as_tensor(x).cuda()).cpu()
+    head = ops.forward(torch.as_tensor(x).cuda()).cpu()[..., :77]
     ref16 = net_n.forward_raw(x, net_n.prec)
     ref32 = net_n.forward_raw(x, "fp32")
     assert head.shape == ref16.shape

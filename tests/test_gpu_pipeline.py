@@ -80,7 +80,7 @@ def test_yolo_call_surface(ood, nets):
     crop = rng.integers(0, 256, (175, 263, 3), dtype=np.uint8)  # partial corner tile: resize + pad path
     res = nets["m416"](crop, conf=0.25)
     assert len(res) == 1
-    head_fn = lambda t: ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+    head_fn = lambda t: ood.ops.forward(torch.as_tensor(t).cuda()).cpu()[..., :77]
     om = opl.OracleModel(nets["n416"], 416, head_fn=head_fn)
     pts, cls, cf = om.predict_rows(crop, 0.25)
     assert len(res[0].obb) == len(cls) and len(cls) > 0
@@ -100,7 +100,7 @@ def test_detect_symbols_vs_oracle_pipeline(ood, nets, H, W, ts, ov, key):
 
     def head_fn(t):
         model._ensure_active()
-        return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+        return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()[..., :77]
     exp = opl.detect_symbols(img, opl.OracleModel(net, ts, head_fn=head_fn), ts, ov)
     got = ood.detect.detect_symbols(img, model, ts, ov)
     assert len(exp) > 5
@@ -113,7 +113,7 @@ def test_process_image_dual_scale_vs_oracle(ood, nets):
     def hf(model):
         def f(t):
             model._ensure_active()
-            return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()
+            return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()[..., :77]
         return f
     oms = [opl.OracleModel(nets["n128"], 128, head_fn=hf(nets["m128"])), opl.OracleModel(nets["n416"], 416, head_fn=hf(nets["m416"]))]
     exp, exp_by_scale = opl.process_image(img, oms)

@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: two gloo ranks shard a tile list, exchange survivor records and must end with the identical,
+tile-ordered record list that a single process produces (world_size 2, 127.0.0.1 rendezvous)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["OBB_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OBB_ROOT"], "tests"))
+    import oriented_object_detection_amd
+    from oriented_object_detection_amd import detect as D, dist as DD
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ntiles = 23
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 9, ntiles); counts[5] = 0; counts[22] = 0
+    tile = np.repeat(np.arange(ntiles), counts).astype(np.int32)
+    n = len(tile)
+    full = D.TileRecords(torch.tensor(tile), torch.tensor(rng.integers(0, 12, n), dtype=torch.int32),
+                         torch.tensor(rng.uniform(0.25, 1, n), dtype=torch.float32), torch.tensor(rng.uniform(0, 416, (n, 8)), dtype=torch.float32))
+    lo, hi = DD.shard_bounds(ntiles, rank, world)
+    m = (full.tile >= lo) & (full.tile < hi)
+    mine = D.TileRecords(full.tile[m], full.cls[m], full.conf[m], full.pts[m])
+    got = DD.all_gather_records(mine)
+    ok = torch.equal(got.tile, full.tile) and torch.equal(got.cls, full.cls) and torch.equal(got.conf, full.conf) and torch.equal(got.pts, full.pts)
+    # empty shard on one rank and empty everywhere
+    e = DD.all_gather_records(mine if rank == 0 else D.TileRecords.empty("cpu"))
+    ok = ok and len(e) == int((full.tile < DD.shard_bounds(ntiles, 0, world)[1]).sum())
+    ok = ok and len(DD.all_gather_records(D.TileRecords.empty("cpu"))) == 0
+    flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 3)
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_record_exchange_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, OBB_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

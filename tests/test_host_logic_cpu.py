@@ -1,0 +1,60 @@
+"""Host-side logic that needs no GPU: letterbox arithmetic, exchange-record packing, shard bounds, config mirror."""
+import numpy as np
+import torch
+
+import oriented_object_detection_amd  # noqa: F401
+from oriented_object_detection_amd import detect as D
+from oriented_object_detection_amd import dist as DD
+from oriented_object_detection_amd import ops
+from oracle import postproc as pp
+
+
+def test_letterbox_shape_matches_oracle_and_scale_boxes():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        imgsz = int(rng.choice([128, 416]))
+        h, w = int(rng.integers(1, imgsz + 1)), int(rng.integers(1, imgsz + 1))
+        p, q = ops.letterbox_shape(h, w, imgsz), pp.letterbox_params(h, w, imgsz)
+        assert (p["out_h"], p["out_w"]) == (q["out_h"], q["out_w"])
+        _, gain, pad = pp.scale_boxes_xywh((q["out_h"], q["out_w"]), torch.zeros((1, 4)), (h, w))
+        assert (p["gain"], p["pad_x"], p["pad_y"]) == (gain, pad[0], pad[1])
+    p = ops.letterbox_shape(416, 416, 416)
+    assert (p["out_h"], p["out_w"], p["gain"], p["pad_x"], p["pad_y"]) == (416, 416, 1.0, 0, 0)
+
+
+def test_config_mirrors_reference_globals():
+    c = D.Config()
+    assert (c.tile_sizes, c.overlaps, c.channels) == ((128, 416), (30, 100), 3)  # Detect_OBB.py:24-28
+    assert (c.iou_threshold, c.iou_thr, c.MAP_MIN_SCORE) == (0.4, 0.25, 0.001)   # :34-36
+    assert (c.margin_for(128), c.margin_for(416), c.margin_for(129)) == (10, 20, 20)  # :156-157
+    assert c.strike_cls == 1 and len(c.CLASS_NAMES) == 12
+    assert (D.CONS_IOU_PARTNER, D.CONS_LOW, D.CONS_HIGH) == (0.40, 0.25, 0.70)  # :349-351
+
+
+def test_tile_records_pack_roundtrip_is_bit_exact():
+    rng = np.random.default_rng(1)
+    n = 37
+    rec = D.TileRecords(torch.tensor(rng.integers(0, 900, n), dtype=torch.int32), torch.tensor(rng.integers(0, 12, n), dtype=torch.int32),
+                        torch.tensor(rng.uniform(0.25, 1, n), dtype=torch.float32), torch.tensor(rng.uniform(-5, 421, (n, 8)), dtype=torch.float32))
+    buf = rec.pack()
+    assert buf.shape == (n, 12) and buf.dtype == torch.int32 and buf.element_size() * 12 == 48  # 48-byte records
+    back = D.TileRecords.unpack(buf)
+    assert torch.equal(back.tile, rec.tile) and torch.equal(back.cls, rec.cls)
+    assert torch.equal(back.conf, rec.conf) and torch.equal(back.pts, rec.pts)
+    assert len(D.TileRecords.unpack(D.TileRecords.empty("cpu").pack())) == 0
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 8, 9, 99, 137):
+        for world in (1, 2, 3, 8):
+            spans = [DD.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_detset_tuple_roundtrip_cpu():
+    dets = [(1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5, 3, float(np.float32(0.7)), 12.0), (0.0,) * 8 + (1, 0.25, 0.0)]
+    ds = D.DetSet.from_tuples(dets, device="cpu")
+    assert ds.to_tuples() == dets

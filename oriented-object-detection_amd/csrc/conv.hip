@@ -19,11 +19,14 @@
 //     bf16(v/255)), i.e. the predictor's preprocess is fused into conv0.
 #include "conv.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace obb {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector: stays in registers where HIP's uint4 struct may not
 
 struct ConvParams {
     const void *in; int64_t in_bs; int in_cs, in_co;
@@ -31,16 +34,21 @@ struct ConvParams {
     const bf16_t *res; int64_t res_bs; int res_cs, res_co;
     const bf16_t *wpk; const float *bias; const bf16_t *lut;
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
-    int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw;
+    int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw, act_bytes;
+    int tpw, ntiles;  // consecutive pixel tiles per workgroup; total pixel tiles (batch included)
+    unsigned in_span_bytes, w_bytes;  // buffer-descriptor ranges: bytes of one image's input slice span; bytes of the packed weights
+    int dbg;  // timing experiments only (OBB_CONV_DBG): 1 skip MFMA loop, 2 skip activation loads, 4 skip SiLU, 8 skip stores, 16 skip weight loads
     float inv_twin, inv_tw;
 };
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU with the hardware exp and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp): its error is far below the 16-bit storage rounding
+__device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
 
 template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16>
-__global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
-    typedef typename HX<F16>::vec8 bf16x8;
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
+    typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) bf16_t s_lut[IN_U8 ? 256 : 8];  // u8 -> half(v/255); sized in multiples of 16 B (statics precede the dynamic region)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
     constexpr int PAD = KS / 2;
@@ -48,214 +56,272 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvParams P) {
     const int THin = (P.TH - 1) * S + KS, TWin = (P.TW - 1) * S + KS;
     const int PST = P.CK * 2 + 16;  // bytes per staged pixel (+16 B pad: spreads consecutive pixels over LDS banks)
     const int cpk = P.CK >> 3;
-
-    int bidx = blockIdx.x;
-    const int tx_i = bidx % P.tiles_x;
-    bidx /= P.tiles_x;
-    const int ty_i = bidx % P.tiles_y;
-    const int b = bidx / P.tiles_y;
+    const int nq = (KS == 3 ? 9 : 1) * cpk;
+    const int in_px = THin * TWin;
+    const int nchunk = in_px << P.sh;
     const int cb = blockIdx.y;
-    const int oy0 = ty_i * P.TH, ox0 = tx_i * P.TW;
-    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    char *wlds = smem + P.act_bytes;
+    if constexpr (IN_U8) s_lut[tid] = P.lut[tid];
 
-    // this lane's pixels (one per M fragment)
-    int pixbase[MF];
-    int opix[MF];  // output pixel linear index inside the image, or -1
+    // ---- tile-independent per-lane state
+    int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (ty << 16 | tx) or -1
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         int p = (wave * MF + mf) * 16 + pl;
         int ty = (int)(((float)p + 0.5f) * P.inv_tw);
         int tx = p - ty * P.TW;
-        bool ok = (p < P.TH * P.TW) && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout);
+        bool ok = p < P.TH * P.TW;
         pixbase[mf] = ok ? ((ty * S) * TWin + tx * S) * PST : 0;
-        opix[mf] = ok ? ((oy0 + ty) * P.Wout + ox0 + tx) : -1;
+        ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
     }
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-        for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    __shared__ __attribute__((aligned(16))) bf16_t s_lut[IN_U8 ? 256 : 8];  // sized in multiples of 16 B: statics precede the dynamic LDS region  // u8 -> half(v/255) table of the network input layer
-    if constexpr (IN_U8) s_lut[tid] = P.lut[tid];
-
-    const int nq = (KS == 3 ? 9 : 1) * cpk;
-    const int in_px = THin * TWin;
-
-    // Staging plan of this thread (16-B chunks idx = tid + k*256 of the [in_px][CK] tile): the pixel -> global offset map is
-    // the same for every channel stage, so it is computed once; stage s only adds s*CK channels.
-    constexpr int MAXLD = 8;
-    int64_t goff[MAXLD];  // element offset of the chunk at stage 0, or -1 when the pixel is outside the image (zero padding)
-    const int nchunk = in_px << P.sh;
+    // staging plan: this thread moves the 16-B chunks idx = tid + k*256 of the [in_px][CK] tile
+    constexpr int MAXLD = (KS == 1) ? 4 : 6;
+    constexpr unsigned NOPIX = 0xffffffffu;
+    int ipos[MAXLD];  // (iy << 16 | ix) inside the input tile, or -1
     if constexpr (!IN_U8) {
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             int idx = tid + k * 256;
-            int pix = idx >> P.sh, c8 = idx & (cpk - 1);
+            int pix = idx >> P.sh;
             int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
             int ix = pix - iy * TWin;
-            int gy = iy0 + iy, gx = ix0 + ix;
-            bool ok = idx < nchunk && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
-            goff[k] = ok ? ((int64_t)gy * P.Win + gx) * P.in_cs + c8 * 8 : -1;
+            ipos[k] = idx < nchunk ? ((iy << 16) | ix) : -1;
         }
     }
-    const bf16_t *src0 = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co;
-    uint4 pre[MAXLD];
+    const int cbase = cb * 16 * NF + g * 4 * NF;
+
+    // ---- tile bookkeeping: a group walks `tpw` consecutive pixel tiles so that prologue, weight staging (single-stage layers)
+    //      and the first activation fetch of the next tile are amortised / overlapped
+    const int t0 = blockIdx.x * P.tpw;
+    const int t1 = min(t0 + P.tpw, P.ntiles);
+    auto tile_origin = [&](int t, int &b, int &oy0, int &ox0) {
+        int tx_i = t % P.tiles_x;
+        int r = t / P.tiles_x;
+        int ty_i = r % P.tiles_y;
+        b = r / P.tiles_y;
+        oy0 = ty_i * P.TH; ox0 = tx_i * P.TW;
+    };
+    // Activations are fetched with buffer loads (one 32-bit byte offset per chunk, descriptor in SGPRs): the descriptor's range
+    // check returns zeros for any offset >= num_records, which is how zero padding and partial channel stages are expressed.
+    unsigned goff[MAXLD];  // BYTE offset of each chunk at stage 0 of the tile being fetched, or NOPIX (-> zeros)
+    __amdgpu_buffer_rsrc_t in_rsrc;
+    auto plan_tile = [&](int t) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+        const bf16_t *base = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co;
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)P.in_span_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            int gy = iy0 + (ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
+            bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+            goff[k] = ok ? (unsigned)((((int64_t)gy * P.Win + gx) * P.in_cs + ((tid + k * 256) & (cpk - 1)) * 8) * 2) : NOPIX;
+        }
+    };
+    u32x4 pre[MAXLD];
     auto load_stage = [&](int stage) {  // global -> registers (asynchronous until the values are used)
         const int crem = P.cin - stage * P.CK;  // channels left (multiple of 8): the last stage may be partial
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             int c8 = (tid + k * 256) & (cpk - 1);
-            pre[k] = make_uint4(0, 0, 0, 0);
-            if (goff[k] >= 0 && c8 * 8 < crem) pre[k] = *reinterpret_cast<const uint4 *>(src0 + goff[k] + stage * P.CK);
+            unsigned off = (c8 * 8 < crem && !(P.dbg & 2)) ? goff[k] : NOPIX;
+            off = off == NOPIX ? NOPIX : off + stage * P.CK * 2;
+            pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
         }
     };
     auto store_stage = [&]() {  // registers -> LDS
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
             int idx = tid + k * 256;
-            if (idx < nchunk) *reinterpret_cast<uint4 *>(smem + (idx >> P.sh) * PST + (idx & (cpk - 1)) * 16) = pre[k];
+            if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + (idx >> P.sh) * PST + (idx & (cpk - 1)) * 16) = pre[k];
         }
     };
-    if constexpr (!IN_U8) load_stage(0);
-
-    for (int stage = 0; stage < P.nstage; ++stage) {
-        __syncthreads();
-        // ---- stage the input tile chunk [in_px][CK] into LDS
-        if constexpr (IN_U8) {
-            const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
-            for (int pix = tid; pix < in_px; pix += 256) {
-                int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
-                int ix = pix - iy * TWin;
-                int gy = iy0 + iy, gx = ix0 + ix;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
-                    const uint8_t *s = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
-                    uint32_t c0 = s_lut[s[P.flip_bgr ? 2 : 0]], c1 = s_lut[s[1]], c2 = s_lut[s[P.flip_bgr ? 0 : 2]];
-                    uint32_t c3 = (P.cin == 4) ? (uint32_t)s_lut[s[3]] : 0u;
-                    v.x = c0 | (c1 << 16);
-                    v.y = c2 | (c3 << 16);
-                }
-                *reinterpret_cast<uint4 *>(smem + pix * PST) = v;
-            }
-            __syncthreads();
-        } else {
-            store_stage();
-            __syncthreads();
-            // prefetch the next channel stage into registers: its HBM/L2 latency hides under this stage's MFMAs
-            if (stage + 1 < P.nstage) load_stage(stage + 1);
+    // Weights of one channel stage (kst * NF fragments of 1 KiB, already in MFMA A-operand lane order) go through LDS too: the
+    // group fetches them ONCE (not once per wave), a whole stage ahead, so neither the L1/TA path nor L2 latency sits in the k-loop.
+    constexpr int MAXW = (KS == 1) ? (NF + 1) / 2 : (NF * 5 * 64 + 255) / 256;  // 1x1: CK <= 64 (kst <= 2); 3x3: CK <= 16 (kst <= 5)
+    const int nwchunk = P.kst * NF * 64;  // 16-B chunks of weights per stage
+    u32x4 prew[MAXW];
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.wpk, 0, (int)P.w_bytes, 0x00020000);
+    auto load_w = [&](int stage) {
+        const unsigned wbase = (unsigned)((cb * P.nstage + stage) * nwchunk) * 16u;
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) {
+            int idx = tid + k * 256;
+            prew[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wbase + (unsigned)(idx < nwchunk ? idx : nwchunk - 1) * 16u, 0, 0);
         }
-
-        // ---- K loop over this stage: weights from global (fragment order), activations from LDS
-        const bf16x8 *wst = reinterpret_cast<const bf16x8 *>(P.wpk) + ((int64_t)(cb * P.nstage + stage) * P.kst) * NF * 64 + lane;
-        bf16x8 wcur[NF], wnxt[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) wcur[f] = wst[f * 64];
-        for (int ks = 0; ks < P.kst; ++ks) {
-            if (ks + 1 < P.kst) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) wnxt[f] = wst[((ks + 1) * NF + f) * 64];
-            }
-            int q = ks * 4 + g;
-            q = q < nq ? q : nq - 1;  // padding k-steps: any valid address, their weights are zero
-            int off;
-            if constexpr (KS == 3) {
-                int tap = q >> P.sh, c0 = q & (cpk - 1);
-                int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-                off = (dy * TWin + dx) * PST + c0 * 16;
-            } else {
-                off = q * 16;
-            }
-            bf16x8 a[MF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const bf16x8 *>(smem + pixbase[mf] + off);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    acc[mf][f] = HX<F16>::mfma(wcur[f], a[mf], acc[mf][f]);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) wcur[f] = wnxt[f];
+    };
+    auto store_w = [&]() {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < MAXW; ++k) {
+            int idx = tid + k * 256;
+            idx = idx < nwchunk ? idx : nwchunk - 1;  // clamped duplicates rewrite the last chunk with its own value (branch-free)
+            *reinterpret_cast<u32x4 *>(wlds + idx * 16) = prew[k];
         }
-    }
+    };
 
-    // ---- epilogue: lane owns couts [cbase, cbase + 4*NF) of pixel opix[mf]
-    const int cbase = cb * 16 * NF + g * 4 * NF;
-    float bias[NF * 4];
+    if (t0 >= t1) return;
+    load_w(0);
+    if constexpr (!IN_U8) { plan_tile(t0); load_stage(0); }
+    bool w_resident = false;
+
+    for (int t = t0; t < t1; ++t) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        f32x4 acc[MF][NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase + f * 4);
-        bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
-    }
-    const bool full = (cbase + 4 * NF <= P.cout);
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-        if (opix[mf] < 0) continue;
-        float v[NF * 4];
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[mf][f][r] + bias[f * 4 + r];
-                if (P.act) x = silu_f(x);
-                v[f * 4 + r] = x;
-            }
-        if (P.res) {
-            const bf16_t *rp = P.res + (int64_t)b * P.res_bs + (int64_t)opix[mf] * P.res_cs + P.res_co + cbase;
-            if (full) {
-#pragma unroll
-                for (int h = 0; h < NF / 2 + (NF == 1); ++h) {
-                    if constexpr (NF == 1) {
-                        uint2 rv = *reinterpret_cast<const uint2 *>(rp);
-                        v[0] += HX<F16>::lo(rv.x); v[1] += HX<F16>::hi(rv.x);
-                        v[2] += HX<F16>::lo(rv.y); v[3] += HX<F16>::hi(rv.y);
-                    } else {
-                        uint4 rv = *reinterpret_cast<const uint4 *>(rp + h * 8);
-                        v[h * 8 + 0] += HX<F16>::lo(rv.x); v[h * 8 + 1] += HX<F16>::hi(rv.x);
-                        v[h * 8 + 2] += HX<F16>::lo(rv.y); v[h * 8 + 3] += HX<F16>::hi(rv.y);
-                        v[h * 8 + 4] += HX<F16>::lo(rv.z); v[h * 8 + 5] += HX<F16>::hi(rv.z);
-                        v[h * 8 + 6] += HX<F16>::lo(rv.w); v[h * 8 + 7] += HX<F16>::hi(rv.w);
+            for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int stage = 0; stage < P.nstage; ++stage) {
+            __syncthreads();
+            // ---- stage this channel chunk of the input tile (and, unless resident, the stage's weights) into LDS
+            if (!w_resident) store_w();
+            if constexpr (IN_U8) {
+                const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+                const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
+                for (int pix = tid; pix < in_px; pix += 256) {
+                    int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
+                    int ix = pix - iy * TWin;
+                    int gy = iy0 + iy, gx = ix0 + ix;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
+                        const uint8_t *s = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
+                        uint32_t c0 = s_lut[s[P.flip_bgr ? 2 : 0]], c1 = s_lut[s[1]], c2 = s_lut[s[P.flip_bgr ? 0 : 2]];
+                        uint32_t c3 = (P.cin == 4) ? (uint32_t)s_lut[s[3]] : 0u;
+                        v.x = c0 | (c1 << 16);
+                        v.y = c2 | (c3 << 16);
                     }
+                    *reinterpret_cast<uint4 *>(smem + pix * PST) = v;
                 }
+                __syncthreads();
             } else {
+                store_stage();
+                __syncthreads();
+                // prefetch into registers: the next channel stage of this tile, or stage 0 of the next tile; the HBM/L2 latency
+                // hides under this stage's MFMAs (and under the epilogue)
+                if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
+                else if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); if (P.nstage > 1) load_w(0); }
+            }
+
+            // ---- K loop over this stage: weight and activation fragments both come from LDS (ds_read_b128, lane-linear / padded rows)
+            for (int ks = 0; ks < ((P.dbg & 1) ? 0 : P.kst); ++ks) {
+                hx8 wcur[NF];
 #pragma unroll
-                for (int c = 0; c < NF * 4; ++c)
-                    if (cbase + c < P.cout) v[c] += HX<F16>::one(rp[c]);
+                for (int f = 0; f < NF; ++f) wcur[f] = *reinterpret_cast<const hx8 *>(wlds + ((ks * NF + f) * 64 + lane) * 16);
+                int q = ks * 4 + g;
+                q = q < nq ? q : nq - 1;  // padding k-steps: any valid address, their weights are zero
+                int off;
+                if constexpr (KS == 3) {
+                    int tap = q >> P.sh, c0 = q & (cpk - 1);
+                    int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+                    off = (dy * TWin + dx) * PST + c0 * 16;
+                } else {
+                    off = q * 16;
+                }
+                hx8 a[MF];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const hx8 *>(smem + pixbase[mf] + off);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[mf][f] = HX<F16>::mfma(wcur[f], a[mf], acc[mf][f]);
             }
         }
-        if constexpr (OUT_F32) {
-            int64_t ob = b, opx = opix[mf];
-            if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }  // 1-D launch, per-image output rows (network head)
-            float *op = (float *)P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
-            if (full && ((P.out_cs | P.out_co) & 3) == 0) {
+        w_resident = (P.nstage == 1);  // single-stage layers keep their weights in LDS for every following tile
+
+        // ---- epilogue: lane owns couts [cbase, cbase + 4*NF) of its pixels: + bias, SiLU, + residual
+        const bool full = (cbase + 4 * NF <= P.cout);
+        constexpr int ROWB = 32 * NF + 16;  // staged output row: 16*NF halves + 16 B pad
+        float bias[NF * 4];
 #pragma unroll
-                for (int f = 0; f < NF; ++f) *reinterpret_cast<float4 *>(op + f * 4) = make_float4(v[f * 4], v[f * 4 + 1], v[f * 4 + 2], v[f * 4 + 3]);
-            } else {
+        for (int f = 0; f < NF; ++f) {
+            float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase + f * 4);
+            bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
+        }
+        if constexpr (!OUT_F32) __syncthreads();  // every wave is done reading the input tile: its LDS becomes the output staging area
 #pragma unroll
-                for (int c = 0; c < NF * 4; ++c)
-                    if (cbase + c < P.cout) op[c] = v[c];
+        for (int mf = 0; mf < MF; ++mf) {
+            int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
+            bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout) && !(P.dbg & 8);
+            if (!ok) continue;
+            const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
+            float v[NF * 4];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[mf][f][r] + bias[f * 4 + r];
+                    if (P.act && !(P.dbg & 4)) x = silu_f(x);
+                    v[f * 4 + r] = x;
+                }
+            if (P.res) {
+                const bf16_t *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + cbase;
+                if (full) {
+#pragma unroll
+                    for (int h = 0; h < NF / 2 + (NF == 1); ++h) {
+                        if constexpr (NF == 1) {
+                            uint2 rv = *reinterpret_cast<const uint2 *>(rp);
+                            v[0] += HX<F16>::lo(rv.x); v[1] += HX<F16>::hi(rv.x);
+                            v[2] += HX<F16>::lo(rv.y); v[3] += HX<F16>::hi(rv.y);
+                        } else {
+                            uint4 rv = *reinterpret_cast<const uint4 *>(rp + h * 8);
+                            v[h * 8 + 0] += HX<F16>::lo(rv.x); v[h * 8 + 1] += HX<F16>::hi(rv.x);
+                            v[h * 8 + 2] += HX<F16>::lo(rv.y); v[h * 8 + 3] += HX<F16>::hi(rv.y);
+                            v[h * 8 + 4] += HX<F16>::lo(rv.z); v[h * 8 + 5] += HX<F16>::hi(rv.z);
+                            v[h * 8 + 6] += HX<F16>::lo(rv.w); v[h * 8 + 7] += HX<F16>::hi(rv.w);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NF * 4; ++c)
+                        if (cbase + c < P.cout) v[c] += HX<F16>::one(rp[c]);
+                }
             }
-        } else {
-            bf16_t *op = (bf16_t *)P.out + (int64_t)b * P.out_bs + (int64_t)opix[mf] * P.out_cs + P.out_co + cbase;
-            if (full) {
+            if constexpr (OUT_F32) {  // network head: fp32 rows of the caller's tensor, float4 per lane
+                int64_t ob = b, opx = opix;
+                if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }  // 1-D launch, per-image output rows
+                float *op = (float *)P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
+                if (full && ((P.out_cs | P.out_co) & 3) == 0) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) *reinterpret_cast<float4 *>(op + f * 4) = make_float4(v[f * 4], v[f * 4 + 1], v[f * 4 + 2], v[f * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NF * 4; ++c)
+                        if (cbase + c < P.cout) op[c] = v[c];
+                }
+            } else {  // 16-bit outputs are staged through LDS so that the global stores below are whole 16-B-per-lane row pieces
+                char *orow = smem + ((wave * MF + mf) * 16 + pl) * ROWB + g * 8 * NF;
                 if constexpr (NF == 1) {
                     uint2 o;
                     o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]);
-                    *reinterpret_cast<uint2 *>(op) = o;
+                    *reinterpret_cast<uint2 *>(orow) = o;
                 } else {
 #pragma unroll
                     for (int h = 0; h < NF / 2; ++h) {
                         uint4 o;
                         o.x = HX<F16>::pack2(v[h * 8 + 0], v[h * 8 + 1]); o.y = HX<F16>::pack2(v[h * 8 + 2], v[h * 8 + 3]);
                         o.z = HX<F16>::pack2(v[h * 8 + 4], v[h * 8 + 5]); o.w = HX<F16>::pack2(v[h * 8 + 6], v[h * 8 + 7]);
-                        *reinterpret_cast<uint4 *>(op + h * 8) = o;
+                        *reinterpret_cast<uint4 *>(orow + h * 16) = o;
                     }
                 }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NF * 4; ++c)
-                    if (cbase + c < P.cout) op[c] = (bf16_t)(HX<F16>::pack2(v[c], 0.f) & 0xffffu);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one fragment at a time: keeps the epilogue's live range at 4*NF values
+        }
+        if constexpr (!OUT_F32) {
+            __syncthreads();
+            // coalesced write-out: consecutive lanes store consecutive 16-B pieces of a pixel's 32*NF-byte output row
+            constexpr int CPP = 2 * NF;  // 16-B chunks per pixel
+            const int npx = P.TH * P.TW;
+            bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + cb * 16 * NF;
+            for (int i = tid; i < npx * CPP && !(P.dbg & 8); i += 256) {
+                int p = i / CPP, ch = i - p * CPP;
+                int ty = (int)(((float)p + 0.5f) * P.inv_tw);
+                int tx = p - ty * P.TW;
+                if (oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
+                if (cb * 16 * NF + ch * 8 + 8 > P.cout) continue;  // cout tail of the last block (cout is a multiple of 8)
+                uint4 o = *reinterpret_cast<const uint4 *>(smem + p * ROWB + ch * 16);
+                *reinterpret_cast<uint4 *>(obase + ((int64_t)(oy0 + ty) * P.Wout + ox0 + tx) * P.out_cs + ch * 8) = o;
             }
         }
     }
@@ -272,16 +338,18 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) 
     t.NF = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
     if (ks == 1) {
         // 1x1: the whole batch is one long pixel row (caller passes Hout = 1, Wout = B*H*W)
+        static const int ck1 = getenv("OBB_CK1") ? atoi(getenv("OBB_CK1")) : 64;
         t.TH = 1; t.MF = 2; t.TW = 64 * t.MF;
-        t.CK = cin >= 64 ? 64 : 32;
+        t.CK = cin >= 128 ? std::min(ck1, 64) : (cin >= 64 ? 64 : 32);
         return t;
     }
     int cin8 = (cin + 7) / 8 * 8;
     if (Hout % 13 == 0 && Wout % 13 == 0) { t.TH = 13; t.TW = 13; t.MF = 3; }
     else if (Hout >= 16 && Wout >= 16) { t.TH = 8; t.TW = 16; t.MF = 2; }
     else { t.TH = 8; t.TW = 8; t.MF = 1; }
+    static const int ck3 = getenv("OBB_CK3") ? std::min(atoi(getenv("OBB_CK3")), 16) : 16;  // weights stage = 5 * NF KiB
     int ck = 1;
-    while (ck * 2 <= cin8 && ck * 2 <= 32) ck *= 2;  // power of two <= min(cin8, 32)
+    while (ck * 2 <= cin8 && ck * 2 <= ck3) ck *= 2;  // power of two <= min(cin8, ck3)
     if (ck < 8) ck = 8;
     if (stride == 2 && ck > 16) ck = 16;             // keep the (2T+1)^2 halo tile small enough for several groups per CU
     t.CK = ck;
@@ -318,10 +386,14 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
     return out;
 }
 
-size_t conv_lds_bytes(const ConvLaunch &L) {
+static size_t conv_act_bytes(const ConvLaunch &L) {
     int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    return (size_t)THin * TWin * (L.CK * 2 + 16);
+    size_t in_tile = (size_t)THin * TWin * (L.CK * 2 + 16);
+    size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);  // epilogue staging re-uses the input tile's LDS
+    return (std::max(in_tile, out_tile) + 15) / 16 * 16;
 }
+
+size_t conv_lds_bytes(const ConvLaunch &L) { return conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024; }
 
 template <int KS, int MF, int NF, bool F16>
 static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
@@ -357,20 +429,39 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout;
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2(L.CK / 8);
-    P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw;
+    P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
+    static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
+    P.dbg = dbg;
+
     int cin_eff = L.in_u8 ? 8 : L.cin;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;
     P.kst = conv_ksteps(L.ks, L.CK);
+    {
+        int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 2;  // from the slice's first element to the end of the image
+        int64_t wb = (int64_t)((L.cout + 16 * L.NF - 1) / (16 * L.NF)) * P.nstage * P.kst * L.NF * 1024;
+        if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
+        P.in_span_bytes = (unsigned)span;
+        P.w_bytes = (unsigned)wb;
+        if (L.ks == 3 && L.CK > 16) return hipErrorInvalidValue;
+    }
     int TWin = (L.TW - 1) * L.stride + L.ks;
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
     if ((1 << P.sh) != L.CK / 8 || L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
     {
         int THin = (L.TH - 1) * L.stride + L.ks;
-        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > 8 * 256) return hipErrorInvalidValue;  // staging plan holds 8 chunks per thread
+        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > (L.ks == 1 ? 4 : 6) * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
+        if (L.ks == 1 && L.CK > 64) return hipErrorInvalidValue;
     }
     int ncb = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
-    dim3 grid((unsigned)((int64_t)L.B * L.tiles_y * L.tiles_x), (unsigned)ncb);
+    int64_t ntiles = (int64_t)L.B * L.tiles_y * L.tiles_x;
+    if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    P.ntiles = (int)ntiles;
+    // tiles per workgroup: keep >= ~8 groups per CU in flight, walk up to 8 consecutive tiles per group beyond that
+    static const int tpw_max = getenv("OBB_TPW") ? atoi(getenv("OBB_TPW")) : 8;
+    int64_t tpw = ntiles * ncb / (256 * 8);
+    P.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(tpw, tpw_max));
+    dim3 grid((unsigned)((ntiles + P.tpw - 1) / P.tpw), (unsigned)ncb);
     size_t lds = conv_lds_bytes(L);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (L.ks == 3) {

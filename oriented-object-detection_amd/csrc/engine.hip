@@ -4,7 +4,9 @@
 // ultralytics==8.3.196 yolo11-obb.yaml).  The graph is lowered to a flat list of fused kernel
 // launches; Concat/chunk/split never materialise: every producer writes into the channel slice of the buffer its
 // consumer reads (TensorRef = base, batch stride, pixel stride, channel offset).
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -540,9 +542,16 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     Plan *P = nullptr;
     int rc = get_plan(ctx, h, w, &P);
     if (rc) return rc;
-    rc = ensure_capacity(ctx, *P, B);
+    // The batch is walked in sub-batches: bounds the activation slab (and keeps every 1-D launch inside 32-bit buffer offsets)
+    static const int max_mb = getenv("OBB_MICROBATCH") ? std::max(1, atoi(getenv("OBB_MICROBATCH"))) : 256;
+    rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
-    return run_forward(ctx, *P, tiles, B, head, (hipStream_t)s);
+    for (int b0 = 0; b0 < B; b0 += max_mb) {
+        int nb = std::min<int>(max_mb, B - b0);
+        rc = run_forward(ctx, *P, tiles + (int64_t)b0 * h * w * ctx->model->ch, nb, head + (int64_t)b0 * P->A * P->no_pad, (hipStream_t)s);
+        if (rc) return rc;
+    }
+    return OBB_OK;
 }
 
 int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_bytes, int64_t *needed) {

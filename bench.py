@@ -76,11 +76,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    # one process per GPU; OBB_FORCE_DEVICE / OBB_DIST_BACKEND exist only to rehearse the N > 1 code path on a 1-GPU box (gloo)
+    local = int(os.environ.get("OBB_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = os.environ.get("OBB_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import make_weights
     import oriented_object_detection_amd  # noqa: F401
@@ -142,7 +148,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev])) if fwd_ev else float("nan")
@@ -157,7 +163,7 @@ def main():
             "dtype": "f16" if args.precision == "f16" else "bf16", "data": "synthetic",
             "config": {"workload": "YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
                                    "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge",
-                       "tiles_per_gpu_per_step": B, "nc": 12, "weights": "synthetic seeded (no checkpoint offline)",
+                       "tiles_per_gpu_per_step": B, "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
                        "survivor_records_per_step": nrec, "final_detections": nmerged},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": None, "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},

@@ -7,6 +7,8 @@
 //   k_gather_tiles / k_letterbox   the tiler's crop (Detect_OBB.py:218-220) and LetterBox(auto=True) preprocess
 // SURVEY.md Appendix A2/A4/A6.  These are HBM/latency-bound kernels: one workgroup per tile, candidates kept in
 // anchor order by ballot/prefix-sum compaction so that ties sort exactly like a stable argsort.
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace obb {
@@ -94,6 +96,36 @@ __device__ __forceinline__ float probiou(const RBox &p, const RBox &q) {
     return 1.0f - hd;
 }
 
+// Cheap decision for pairs that are nowhere near the threshold: the same Bhattacharyya distance evaluated with the hardware
+// reciprocal / log / sqrt (relative error ~1e-6).  probiou >= thr  <=>  bd <= BDmax (monotone), so bd_fast outside a guard band
+// around BDmax decides the pair; anything inside the band (|bd_fast - BDmax| <= 1e-4 + 1e-3 * BDmax) is re-evaluated exactly.
+// returns +1 hit, -1 miss, 0 undecided
+__device__ __forceinline__ int probiou_fast_decision(const RBox &p, const RBox &q, float bdmax) {
+    const float eps = 1e-7f;
+    float sa = p.A + q.A, sb = p.B + q.B, sc = p.C + q.C;
+    float den = sa * sb - sc * sc;
+    float dy = p.y - q.y, dx = p.x - q.x;
+    float inv = __frcp_rn(den + eps);
+    float t1 = (sa * (dy * dy) + sb * (dx * dx)) * inv * 0.25f;
+    float t2 = (sc * (q.x - p.x) * dy) * inv * 0.5f;
+    float t3 = __logf(den * __frcp_rn(4.0f * __fsqrt_rn(p.det * q.det) + eps) + eps) * 0.5f;
+    float bd = t1 + t2 + t3;
+    float band = 1e-4f + 1e-3f * bdmax;
+    if (!(bd == bd)) return 0;  // NaN: let the exact path decide
+    if (bd > bdmax + band) return -1;
+    if (bd < bdmax - band) return 1;
+    return 0;
+}
+
+static bool nms_exact_only() { static const bool v = getenv("OBB_NMS_EXACT") && atoi(getenv("OBB_NMS_EXACT")); return v; }
+
+static float probiou_bdmax(float thr) {
+    if (nms_exact_only()) return -1.0f;
+    double s = 1.0 + 1e-7 - (1.0 - (double)thr) * (1.0 - (double)thr);
+    if (!(thr > 1e-3f) || s <= 0.0 || s >= 1.0) return -1.0f;  // disables the fast path
+    return (float)(-log(s));
+}
+
 // Conservative far-apart test.  probiou >= thr  <=>  bd <= BDmax = -log(1 + eps - (1 - thr)^2), and
 // bd >= t1 + t2 = d^T (S1 + S2)^-1 d / 4 >= |d|^2 / (4 trace(S1 + S2))  (t3 >= 0 by AM-GM on the determinants).
 // So |d|^2 > kq * (tr1 + tr2) with kq = 4 * BDmax * 1.05 proves probiou < thr without evaluating it; pairs anywhere near the
@@ -104,6 +136,7 @@ __device__ __forceinline__ bool far_apart(const RBox &p, const RBox &q, float kq
 }
 
 static float far_apart_factor(float thr) {
+    if (getenv("OBB_NMS_EXACT") && atoi(getenv("OBB_NMS_EXACT"))) return INFINITY;
     double s = 1.0 + 1e-7 - (1.0 - (double)thr) * (1.0 - (double)thr);
     if (!(thr > 1e-3f) || s <= 0.0 || s >= 1.0) return INFINITY;  // never reject
     return (float)(4.0 * -log(s) * 1.05);
@@ -139,7 +172,7 @@ struct NmsScratch {  // per tile, capacity A rows each
 // more anchors than fit use the same code on global scratch.
 template <bool LDS_RESIDENT>
 __global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pred, int A, int nc, float conf_thres, float iou_thres,
-                                                  int max_det, int max_nms, float kq, NmsScratch S, float *__restrict__ out,
+                                                  int max_det, int max_nms, float kq, float bdmax, NmsScratch S, float *__restrict__ out,
                                                   int32_t *__restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
     __shared__ int wave_tot[16];
@@ -220,7 +253,10 @@ __global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pre
                 bool h = false;
                 if (i < r && !(skip_other_cls && scls[i] != cq)) {
                     RBox p = rb[i];
-                    if (!far_apart(p, q, kq)) h = probiou(p, q) >= iou_thres;
+                    if (!far_apart(p, q, kq)) {
+                        int dec = bdmax > 0.0f ? probiou_fast_decision(p, q, bdmax) : 0;
+                        h = dec > 0 || (dec == 0 && probiou(p, q) >= iou_thres);
+                    }
                 }
                 if (__ballot(h)) { hit = true; break; }
             }
@@ -419,10 +455,10 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
             attr_set = true;
         }
         hipLaunchKernelGGL(k_nms_tile<true>, dim3((unsigned)B), dim3(1024), lds, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
-                           30000, far_apart_factor(iou_thres), S, out, count);
+                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count);
     } else {
         hipLaunchKernelGGL(k_nms_tile<false>, dim3((unsigned)B), dim3(1024), 0, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
-                           30000, far_apart_factor(iou_thres), S, out, count);
+                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count);
     }
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;

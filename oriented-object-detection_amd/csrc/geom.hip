@@ -71,25 +71,39 @@ __global__ __launch_bounds__(256) void k_iou_matrix(const double *__restrict__ a
 
 __device__ __forceinline__ double sort_key(double k) { return isnan(k) ? -INFINITY : k; }
 
-// order[rank(i)] = i, rank(i) = #{j: key_j > key_i} + #{j < i: key_j == key_i}  (stable, descending)
-__global__ __launch_bounds__(256) void k_rank_sort(const double *__restrict__ key, int64_t n, int32_t *__restrict__ order) {
-    __shared__ double sk[1024];
+// order[rank(i)] = i, rank(i) = #{j: key_j > key_i} + #{j < i: key_j == key_i}  (stable, descending).
+// 2-D decomposition: block (x, y) counts, for its 256 rows i, the keys of j-slice y that precede them; partial counts are
+// summed with integer atomics (exact, order-independent), a second pass scatters.  Keys are compared as monotone uint64
+// images of the doubles (integer compares; -0.0 == +0.0 and NaN -> -inf handled in the mapping).
+__device__ __forceinline__ unsigned long long sort_image(double k) {
+    k = sort_key(k);
+    if (k == 0.0) k = 0.0;  // -0.0 -> +0.0
+    unsigned long long u = (unsigned long long)__double_as_longlong(k);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+static constexpr int kRankJSlice = 2048;
+
+__global__ __launch_bounds__(256) void k_rank_count(const double *__restrict__ key, int64_t n, int32_t *__restrict__ rank) {
+    __shared__ unsigned long long sk[kRankJSlice];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double ki = (i < n) ? sort_key(key[i]) : 0.0;
-    int32_t rank = 0;
-    for (int64_t j0 = 0; j0 < n; j0 += 1024) {
-        int cnt = (int)((n - j0) < 1024 ? (n - j0) : 1024);
-        __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += 256) sk[t] = sort_key(key[j0 + t]);
-        __syncthreads();
-        if (i < n) {
-            for (int t = 0; t < cnt; ++t) {
-                double kj = sk[t];
-                rank += (kj > ki) | ((kj == ki) & (j0 + t < i));
-            }
-        }
-    }
-    if (i < n) order[rank] = (int32_t)i;
+    int64_t j0 = (int64_t)blockIdx.y * kRankJSlice;
+    int cnt = (int)((n - j0) < kRankJSlice ? (n - j0) : kRankJSlice);
+    for (int t = threadIdx.x; t < cnt; t += 256) sk[t] = sort_image(key[j0 + t]);
+    __syncthreads();
+    if (i >= n) return;
+    unsigned long long ki = sort_image(key[i]);
+    int32_t r = 0;
+    // ties: j < i counts.  The slice lies entirely before i, entirely after, or straddles it.
+    if (j0 + cnt <= i) { for (int t = 0; t < cnt; ++t) r += (sk[t] >= ki); }
+    else if (j0 > i) { for (int t = 0; t < cnt; ++t) r += (sk[t] > ki); }
+    else { for (int t = 0; t < cnt; ++t) r += (sk[t] > ki) | ((sk[t] == ki) & (j0 + t < i)); }
+    if (r) atomicAdd(&rank[i], r);
+}
+
+__global__ __launch_bounds__(256) void k_rank_scatter(const int32_t *__restrict__ rank, int64_t n, int32_t *__restrict__ order) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[rank[i]] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------ dense NMS (n > kSegMax)
@@ -556,7 +570,13 @@ int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *or
     OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1ll << 31), "obb_sort_desc_stable: bad n");
     if (n == 0) return OBB_OK;
     OBB_REQUIRE(ctx, key && order, "obb_sort_desc_stable: NULL buffer");
-    hipLaunchKernelGGL(k_rank_sort, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, key, n, order);
+    int32_t *rank = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * (size_t)n);
+    if (!rank) return set_error(ctx, OBB_ERR_HIP, "obb_sort_desc_stable: workspace allocation failed");
+    OBB_REQUIRE(ctx, cdiv(n, kRankJSlice) <= 65535, "obb_sort_desc_stable: n too large");
+    OBB_HIP(ctx, hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, (hipStream_t)s));
+    hipLaunchKernelGGL(k_rank_count, dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(n, kRankJSlice)), dim3(256), 0, (hipStream_t)s, key, n, rank);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_rank_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const int32_t *)rank, n, order);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

@@ -27,19 +27,22 @@ def all_gather_records(rec, group=None):
     if world == 1:
         return rec
     dev = rec.tile.device
-    buf = rec.pack()
-    n = torch.tensor([buf.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    # RCCL ("nccl") exchanges device buffers directly over xGMI; the gloo rehearsal path (CPU tests, single-GPU boxes) stages
+    # through host memory.
+    xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf = rec.pack().to(xdev)
+    n = torch.tensor([buf.shape[0]], dtype=torch.int64, device=xdev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
     counts = [int(c.item()) for c in counts]
     mx = max(counts)
     if mx == 0:
         return rec
-    padded = torch.zeros((mx, 12), dtype=torch.int32, device=dev)
+    padded = torch.zeros((mx, 12), dtype=torch.int32, device=xdev)
     padded[: buf.shape[0]] = buf
-    outs = [torch.zeros((mx, 12), dtype=torch.int32, device=dev) for _ in range(world)]
+    outs = [torch.zeros((mx, 12), dtype=torch.int32, device=xdev) for _ in range(world)]
     dist.all_gather(outs, padded, group=group)
-    return TileRecords.unpack(torch.cat([o[:c] for o, c in zip(outs, counts)], 0).contiguous())
+    return TileRecords.unpack(torch.cat([o[:c] for o, c in zip(outs, counts)], 0).contiguous().to(dev))
 
 
 def detect_symbols_distributed(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256, group=None):

@@ -1,0 +1,111 @@
+"""The mAP instrument of Detect_OBB.py (row a15 of SURVEY.md section 8) on the GPU polygon-IoU kernel:
+
+    _load_gt_as_pixels        :436-454   (labels: `cls x1 y1 ... x4 y4` normalised -> pixels; image size passed in, no cv2)
+    gather_detections_and_gts :501-510
+    compute_pr_for_class      :512-565   (score-ordered greedy matching, strict `iou > best_iou`, then `best_iou >= thr`)
+    compute_ap_from_pr        :489-499   (all-point interpolation)
+    evaluate_map              :574-607   (mean over GT-present classes, classes without detections count as AP 0)
+
+All detection x ground-truth IoUs of one (class, image) pair come from one obb_poly_iou_matrix launch; the greedy matching is the
+reference's own sequential loop over that matrix (control flow, no arithmetic)."""
+import numpy as np
+import torch
+
+from . import ops
+
+MAP_MIN_SCORE = 0.001  # Detect_OBB.py:34
+
+
+def load_gt_as_pixels(label_path, w, h):
+    gts = []
+    with open(label_path, "r") as f:
+        for line in f:
+            parts = line.strip().split()
+            if len(parts) != 9:
+                continue
+            vals = list(map(float, parts[1:]))
+            pts = [c for i in range(0, 8, 2) for c in (vals[i] * w, vals[i + 1] * h)]
+            gts.append({"cls": int(parts[0]), "pts": pts})
+    return gts
+
+
+def compute_ap_from_pr(recall, precision):
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([0.0], precision, [0.0]))
+    for i in range(mpre.size - 2, -1, -1):
+        mpre[i] = max(mpre[i], mpre[i + 1])
+    idx = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[idx + 1] - mrec[idx]) * mpre[idx + 1]))
+
+
+def compute_pr_for_class(dets, gts, iou_thr=0.5, device=None):
+    """dets: list of {"image_id", "score", "bbox"(8)}; gts: {image_id: [bbox8, ...]} -> (precision, recall, ap, TP, FP, FN)"""
+    npos = sum(len(v) for v in gts.values())
+    if npos == 0:
+        return np.array([0.0]), np.array([0.0]), 0.0, 0, 0, 0
+    dets_sorted = sorted(dets, key=lambda x: x["score"], reverse=True)
+    if len(dets_sorted) == 0:
+        return np.array([0.0]), np.array([0.0]), 0.0, 0, 0, npos
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    # one IoU matrix per image (detections of that image x its ground truths)
+    by_img = {}
+    for i, d in enumerate(dets_sorted):
+        by_img.setdefault(d["image_id"], []).append(i)
+    iou_rows = {}
+    for img, idxs in by_img.items():
+        g = gts.get(img, [])
+        if not g:
+            continue
+        a = torch.tensor([list(dets_sorted[i]["bbox"][:8]) for i in idxs], dtype=torch.float64, device=dev)
+        b = torch.tensor([list(x) for x in g], dtype=torch.float64, device=dev)
+        m = ops.poly_iou_matrix(a, b).cpu().numpy()
+        for r, i in enumerate(idxs):
+            iou_rows[i] = m[r]
+    tp, fp = np.zeros(len(dets_sorted)), np.zeros(len(dets_sorted))
+    matched = {img: np.zeros(len(v), dtype=bool) for img, v in gts.items()}
+    for i, det in enumerate(dets_sorted):
+        img = det["image_id"]
+        best_iou, best_j = 0.0, -1
+        row = iou_rows.get(i)
+        if row is not None:
+            for j in range(len(row)):
+                if matched[img][j]:
+                    continue
+                if row[j] > best_iou:
+                    best_iou, best_j = row[j], j
+        if best_iou >= iou_thr and best_j >= 0:
+            tp[i] = 1
+            matched[img][best_j] = True
+        else:
+            fp[i] = 1
+    tp_cum, fp_cum = np.cumsum(tp), np.cumsum(fp)
+    recall = tp_cum / (npos + 1e-9)
+    precision = tp_cum / (tp_cum + fp_cum + 1e-9)
+    ap = compute_ap_from_pr(recall, precision)
+    return precision, recall, ap, int(tp_cum[-1]), int(fp_cum[-1]), npos - int(tp_cum[-1])
+
+
+def gather_detections_and_gts(dets_source, gt_source, cls_id):
+    dets, gts = [], {}
+    for img, gt_boxes in gt_source.items():
+        for d in dets_source.get(img, []):
+            if int(d[8]) == cls_id and d[9] >= MAP_MIN_SCORE:
+                dets.append({"image_id": img, "score": float(d[9]), "bbox": d[:8]})
+        gts[img] = [g["pts"] for g in gt_boxes if g["cls"] == cls_id]
+    return dets, gts
+
+
+def evaluate_map(dets_source, gt_source, iou_list=None):
+    """dets_source: {image: [11-tuples]}, gt_source: {image: [{"cls", "pts"}]} -> the reference's result dict"""
+    if iou_list is None:
+        iou_list = [0.5] + [round(0.5 + 0.05 * i, 2) for i in range(1, 10)]
+    class_ids = sorted({int(g["cls"]) for gl in gt_source.values() for g in gl})
+    per_iou = {}
+    for iou in iou_list:
+        aps = []
+        for cid in class_ids:
+            dets, gts = gather_detections_and_gts(dets_source, gt_source, cid)
+            aps.append(compute_pr_for_class(dets, gts, iou_thr=iou)[2])
+        per_iou[iou] = float(np.mean(aps)) if aps else 0.0
+    return {"mAP@0.5": per_iou.get(0.5, 0.0), "mAP@[0.5:0.95]": float(np.mean([per_iou[i] for i in iou_list])) if iou_list else 0.0,
+            "per_iou": per_iou}

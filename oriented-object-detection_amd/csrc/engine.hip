@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 
 #include "ctx.h"
 #include "nnops.h"
@@ -63,7 +64,18 @@ struct Plan {
     void *slab = nullptr;
     int64_t bytes_per_img = 0;
     double macs_per_img = 0;
+    // hipGraph cache: the ~110 launches of one forward are captured once per (sub-batch size, input pointer, output pointer) and
+    // replayed; a key is captured the second time it is seen (the first run is eager: it also performs one-time attribute setup)
+    typedef std::tuple<int, const void *, void *> GraphKey;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, int> seen;
+    void drop_graphs() {
+        for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+        seen.clear();
+    }
     ~Plan() {
+        drop_graphs();
         for (void *p : dev_allocs) (void)hipFree(p);
         if (slab) (void)hipFree(slab);
     }
@@ -394,6 +406,7 @@ static int ensure_capacity(obb_ctx *ctx, Plan &P, int B) {
     }
     void *slab = nullptr;
     OBB_HIP(ctx, hipDeviceSynchronize());
+    P.drop_graphs();  // captured launches point into the old slab
     if (P.slab) { (void)hipFree(P.slab); P.slab = nullptr; P.cap = 0; }
     OBB_HIP(ctx, hipMalloc(&slab, (size_t)off + 256));
     P.slab = slab;
@@ -546,9 +559,38 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     static const int max_mb = getenv("OBB_MICROBATCH") ? std::max(1, atoi(getenv("OBB_MICROBATCH"))) : 256;
     rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
+    static const bool use_graph = !(getenv("OBB_GRAPH") && atoi(getenv("OBB_GRAPH")) == 0);
+    hipStream_t st = (hipStream_t)s;
     for (int b0 = 0; b0 < B; b0 += max_mb) {
         int nb = std::min<int>(max_mb, B - b0);
-        rc = run_forward(ctx, *P, tiles + (int64_t)b0 * h * w * ctx->model->ch, nb, head + (int64_t)b0 * P->A * P->no_pad, (hipStream_t)s);
+        const uint8_t *tp = tiles + (int64_t)b0 * h * w * ctx->model->ch;
+        float *hp = head + (int64_t)b0 * P->A * P->no_pad;
+        Plan::GraphKey key(nb, (const void *)tp, (void *)hp);
+        auto git = P->graphs.find(key);
+        if (use_graph && git != P->graphs.end()) {
+            OBB_HIP(ctx, hipGraphLaunch(git->second, st));
+            continue;
+        }
+        bool capture = use_graph && P->seen[key]++ >= 1 && P->graphs.size() < 64;
+        if (capture && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); capture = false; }
+        rc = run_forward(ctx, *P, tp, nb, hp, st);
+        if (capture) {
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc == OBB_OK && e == hipSuccess && g) {
+                hipGraphExec_t ge = nullptr;
+                if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+                    P->graphs[key] = ge;
+                    (void)hipGraphDestroy(g);
+                    OBB_HIP(ctx, hipGraphLaunch(ge, st));
+                    continue;
+                }
+                (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();
+            if (rc) return rc;
+            rc = run_forward(ctx, *P, tp, nb, hp, st);  // capture unavailable: run eagerly
+        }
         if (rc) return rc;
     }
     return OBB_OK;

@@ -189,15 +189,22 @@ def model_info(h, w, device=None):
     return {"nc": nc.value, "ch": ch.value, "anchors": a.value, "nconv": n.value}
 
 
-def forward(tiles):
-    """tiles uint8 [B,h,w,ch] NHWC (BGR for 3-channel input, as the reference passes crops) -> raw head [B,A,64+nc+1] f32."""
+def forward(tiles, out=None):
+    """tiles uint8 [B,h,w,ch] NHWC (BGR for 3-channel input, as the reference passes crops) -> raw head [B,A,NO] f32.
+    `out`: optional preallocated head tensor (stable input/output addresses let the library replay its captured hipGraph)."""
     t = _chk(tiles, torch.uint8, "tiles")
     B, h, w, ch = t.shape
     info = model_info(h, w, t.device)
     if ch != info["ch"]:
         raise ValueError(f"forward: model expects {info['ch']} input channels, got {ch}")
     no = 64 + info["nc"] + 1
-    head = torch.zeros((B, info["anchors"], (no + 3) // 4 * 4), dtype=torch.float32, device=t.device)
+    shape = (B, info["anchors"], (no + 3) // 4 * 4)
+    if out is not None:
+        if tuple(out.shape) != shape:
+            raise ValueError(f"forward: out must have shape {shape}")
+        head = _chk(out, torch.float32, "out")
+    else:
+        head = torch.zeros(shape, dtype=torch.float32, device=t.device)
     _call("obb_forward", ctx(t.device), _p(t), B, h, w, _p(head), _stream())
     return head  # rows padded to a multiple of 4 floats; [..., :64+nc+1] are the logits
 

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 from oracle.yolo11_obb import Yolo11OBB
 import oriented_object_detection_amd
 from oriented_object_detection_amd import ops

@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "report":
     print("total %.1f us, forwards seen %d" % (tot, nf))
 else:
     import torch
-    sys.path.insert(0, "tests")
+    sys.path.insert(0, "tests"); sys.path.insert(0, ".")
     import make_weights, os
     import oriented_object_detection_amd
     from oriented_object_detection_amd import ops

@@ -1,5 +1,5 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import make_weights
 import oriented_object_detection_amd
 from oriented_object_detection_amd import ops

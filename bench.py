@@ -43,6 +43,7 @@ def cpu_baseline(budget_s=15.0):
     + oracle post-processing + C geometry), timed on this box's host cores on a bounded sample."""
     from oracle import pipeline as opl
     from oracle.yolo11_obb import Yolo11OBB
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))  # more threads only add synchronisation cost on these small convolutions
     net = Yolo11OBB("n", nc=12, ch=3, seed=0)
     om = opl.OracleModel(net, 416, "fp32")
     rng = np.random.default_rng(0)

@@ -6,8 +6,9 @@ A "step" is one pass of the hot path over one batch of synthetic 416x416x3 tiles
     uint8 tiles -> fused preprocess + YOLO11n-OBB forward (MFMA implicit-GEMM convs) -> decode -> ProbIoU Fast-NMS
     -> result construction -> border filter -> per-tile polygon-IoU merge -> [N>1: RCCL all-gather of survivor records]
     -> final whole-batch polygon-IoU merge (the fusion step of process_image).
-Nothing is cached or skipped between steps.  With --gpus N every rank processes its own batch (weak scaling) and the
-survivors of all ranks are exchanged every step exactly as the multi-GPU tiler does.
+Nothing is cached or skipped between steps; consecutive steps are software-pipelined on two HIP streams (the forward of step
+k+1 overlaps the post-processing of step k; --no-pipeline disables it).  With --gpus N every rank processes its own batch (weak
+scaling) and the survivors of all ranks are exchanged every step exactly as the multi-GPU tiler does.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (MFMA, for the conv kernel family: algorithmic FLOPs of
 the forward / HIP-event time of the forward) and "cpu_baseline" (the CPU restatement of the same path, bounded sample).
@@ -68,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 256)), help="tiles per GPU per step")
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("OBB_BENCH_CHUNKS", 1)), help="sub-batches per step (forward / post-processing overlap)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -111,63 +112,78 @@ def main():
     tile_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
     fwd_ev = []
 
-    # The batch is walked in `chunks` sub-batches on two HIP streams: the forward of chunk k+1 (MFMA/HBM bound, whole chip) overlaps
-    # the per-tile post-processing of chunk k (latency bound, a few workgroups).  Same work, same results, no step-to-step reuse.
-    nch = max(1, min(args.chunks, B))
-    bounds = [(i * B // nch, (i + 1) * B // nch) for i in range(nch)]
+    # Two HIP streams, software-pipelined over steps: the forward of step k+1 (whole chip, HBM/MFMA bound) is enqueued before the
+    # host starts the post-processing of step k (per-tile NMS / merge kernels: latency bound, a few workgroups, host-visible counts).
+    # Every step still performs all of its work inside the timed region; nothing is reused between steps (heads are double-buffered).
     s_fwd, s_post = torch.cuda.Stream(), torch.cuda.Stream()
-    head_bufs = [torch.zeros((hi - lo, 3549, 80), dtype=torch.float32, device=dev) for (lo, hi) in bounds]  # stable addresses -> graph replay
+    head_bufs = [torch.zeros((B, 3549, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
     md = cfg.max_det
 
-    def step(timed):
-        cur = torch.cuda.current_stream()
-        s_fwd.wait_stream(cur)
-        s_post.wait_stream(cur)
-        heads, evs = [], []
+    def launch_forward(k, timed):
         with torch.cuda.stream(s_fwd):
             model._ensure_active()
-            for (lo, hi), hb in zip(bounds, head_bufs):
-                e0 = torch.cuda.Event(enable_timing=timed)
-                e1 = torch.cuda.Event(enable_timing=timed)
-                e0.record()
-                heads.append(ops.forward(tiles[lo:hi], out=hb))
-                e1.record()
-                evs.append((e0, e1))
+            e0, e1 = torch.cuda.Event(enable_timing=timed), torch.cuda.Event(enable_timing=timed)
+            e0.record()
+            head = ops.forward(tiles, out=head_bufs[k % 2])
+            e1.record()
         if timed:
-            fwd_ev.append(evs)
-        recs = []
+            fwd_ev.append((e0, e1))
+        return head, e1
+
+    def postprocess(head, ready):
         with torch.cuda.stream(s_post):
-            for (lo, hi), head, (e0, e1) in zip(bounds, heads, evs):
-                s_post.wait_event(e1)
-                det, cnt = ops.decode_nms(head, 416, 416, cfg.conf_predict, cfg.iou_nms, md)
-                valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
-                rows = torch.nonzero(valid).squeeze(1)
-                if rows.numel():
-                    d = det.reshape(-1, 7)[rows].contiguous()
-                    slot = (rows // md).long() + lo
-                    _, pts = ops.results(d, None)
-                    recs.append(D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), tile_ids[slot].contiguous(), rects_dev, cfg, 416))
-            if recs:
-                rec = D.TileRecords(torch.cat([r.tile for r in recs]), torch.cat([r.cls for r in recs]), torch.cat([r.conf for r in recs]),
-                                    torch.cat([r.pts for r in recs]))
+            s_post.wait_event(ready)
+            det, cnt = ops.decode_nms(head, 416, 416, cfg.conf_predict, cfg.iou_nms, md)
+            valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
+            rows = torch.nonzero(valid).squeeze(1)
+            if rows.numel():
+                d = det.reshape(-1, 7)[rows].contiguous()
+                slot = (rows // md).long()
+                _, pts = ops.results(d, None)
+                rec = D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), tile_ids[slot].contiguous(), rects_dev, cfg, 416)
             else:
                 rec = D.TileRecords.empty(dev)
             if world > 1:
                 rec = DD.all_gather_records(rec)
             ds = D.records_to_detset(rec, rects_dev, cfg, 416)
             merged, _ = D.merge_detections_device(ds, cfg.iou_threshold)
+            done = torch.cuda.Event()
+            done.record()
+        return len(rec), len(merged), done
+
+    def run_steps(n, timed):
+        cur = torch.cuda.current_stream()
+        s_fwd.wait_stream(cur)
+        s_post.wait_stream(cur)
+        res, pending, dones = (0, 0), None, [None, None]
+        for k in range(n):
+            if dones[k % 2] is not None:
+                s_fwd.wait_event(dones[k % 2])  # head buffer k%2 is free once step k-2 has been post-processed
+            f = launch_forward(k, timed)
+            if pending is not None:
+                r = postprocess(*pending[1])
+                res, dones[pending[0] % 2] = r[:2], r[2]
+                if not args.pipeline:
+                    s_fwd.wait_event(r[2])
+            pending = (k, f)
+            if not args.pipeline:  # strictly sequential variant: finish step k before anything of step k+1 is enqueued
+                r = postprocess(*pending[1])
+                res, dones[k % 2] = r[:2], r[2]
+                s_fwd.wait_event(r[2])
+                pending = None
+        if pending is not None:
+            r = postprocess(*pending[1])
+            res = r[:2]
         cur.wait_stream(s_post)
         cur.wait_stream(s_fwd)
-        return len(rec), len(merged)
+        return res
 
-    for _ in range(args.warmup):
-        nrec, nmerged = step(False)
+    nrec, nmerged = run_steps(args.warmup, False) if args.warmup else (0, 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nrec, nmerged = step(True)
+    nrec, nmerged = run_steps(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,7 +192,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    fwd_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in evs) for evs in fwd_ev])) if fwd_ev else float("nan")
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev])) if fwd_ev else float("nan")
 
     if rank == 0:
         tiles_per_s = world * B * args.steps / dt
@@ -188,7 +204,7 @@ def main():
             "dtype": "f16" if args.precision == "f16" else "bf16", "data": "synthetic",
             "config": {"workload": "YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
                                    "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge",
-                       "tiles_per_gpu_per_step": B, "chunks_per_step": nch, "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
+                       "tiles_per_gpu_per_step": B, "step_pipelining": bool(args.pipeline), "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
                        "survivor_records_per_step": nrec, "final_detections": nmerged},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": None, "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},

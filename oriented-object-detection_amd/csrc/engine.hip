@@ -51,6 +51,9 @@ struct Op {
     int act = 0;
     int N = 0, nh = 0, kd = 0, hd = 0;  // OP_ATTN
     int head_level = -1;     // >= 0: output goes to the caller's head tensor at this level
+    int lane = 0;            // 0 = caller's stream; 1..3 = side stream of a head branch (box / class / angle)
+    int wait_feat = -1;      // >= 0: first op of a head branch at this pyramid level: wait until its input feature map exists
+    int signal_feat = -1;    // >= 0: this op produces the feature map of that pyramid level
 };
 
 struct Plan {
@@ -66,6 +69,8 @@ struct Plan {
     double macs_per_img = 0;
     // hipGraph cache: the ~110 launches of one forward are captured once per (sub-batch size, input pointer, output pointer) and
     // replayed; a key is captured the second time it is seen (the first run is eager: it also performs one-time attribute setup)
+    hipStream_t lanes[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     typedef std::tuple<int, const void *, void *> GraphKey;
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> seen;
@@ -76,6 +81,11 @@ struct Plan {
     }
     ~Plan() {
         drop_graphs();
+        for (int i = 0; i < 3; ++i) {
+            if (lanes[i]) (void)hipStreamDestroy(lanes[i]);
+            if (ev_feat[i]) (void)hipEventDestroy(ev_feat[i]);
+            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+        }
         for (void *p : dev_allocs) (void)hipFree(p);
         if (slab) (void)hipFree(slab);
     }
@@ -348,12 +358,15 @@ struct Builder {
         upsample(x13, H16, W16, sub(cat16, 0, c512));
         int b16 = buf(H8, W8, c256, "x16");
         c3k2(16, whole(cat16), H8, W8, whole(b16), n2, big, 0.5);
+        P.ops.back().signal_feat = 0;
         conv("model.17", whole(b16), H8, W8, sub(cat19, 0, c256));
         int b19 = buf(H16, W16, c512, "x19");
         c3k2(19, whole(cat19), H16, W16, whole(b19), n2, big, 0.5);
+        P.ops.back().signal_feat = 1;
         conv("model.20", whole(b19), H16, W16, sub(cat22, 0, c512));
         int b22 = buf(H32, W32, c1024, "x22");
         c3k2(22, whole(cat22), H32, W32, whole(b22), n2, true, 0.5);
+        P.ops.back().signal_feat = 2;
         // OBB head
         const int chs[3] = {c256, c512, c1024};
         const int feats[3] = {b16, b19, b22};
@@ -364,14 +377,23 @@ struct Builder {
         int off = 0;
         for (int i = 0; i < 3; ++i) { P.lvl_off[i] = off; off += Hs[i] * Ws[i]; }
         P.A = off;
+        // The nine head chains (3 levels x {box, class, angle}) only depend on their level's feature map: each branch type runs on
+        // its own side stream, so the P3 head overlaps layers 17-22 and the small P4/P5 kernels overlap each other.
+        auto mark_branch = [&](size_t first, int lane, int level) {
+            for (size_t k = first; k < P.ops.size(); ++k) P.ops[k].lane = lane;
+            P.ops[first].wait_feat = level;
+        };
         for (int i = 0; i < 3; ++i) {
+            size_t first_op = P.ops.size();
             std::string p = "model.23.cv2." + std::to_string(i);
             int t1 = buf(Hs[i], Ws[i], c2, p + ".t1"), t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(t1));
             conv(p + ".1", whole(t1), Hs[i], Ws[i], whole(t2));
             conv(p + ".2", whole(t2), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i);
+            mark_branch(first_op, 1, i);
         }
         for (int i = 0; i < 3; ++i) {
+            size_t first_op = P.ops.size();
             std::string p = "model.23.cv3." + std::to_string(i);
             int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1"), e1 = buf(Hs[i], Ws[i], c3, p + ".e1"), d2 = buf(Hs[i], Ws[i], c3, p + ".d2"),
                 e2 = buf(Hs[i], Ws[i], c3, p + ".e2");
@@ -380,13 +402,16 @@ struct Builder {
             dwconv(p + ".1.0", whole(e1), Hs[i], Ws[i], whole(d2));
             conv(p + ".1.1", whole(d2), Hs[i], Ws[i], whole(e2));
             conv(p + ".2", whole(e2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i);
+            mark_branch(first_op, 2, i);
         }
         for (int i = 0; i < 3; ++i) {
+            size_t first_op = P.ops.size();
             std::string p = "model.23.cv4." + std::to_string(i);
             int u1 = buf(Hs[i], Ws[i], c4, p + ".u1"), u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
             conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
             conv(p + ".2", whole(u2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i);
+            mark_branch(first_op, 3, i);
         }
         for (const char *nm : {"x0", "x1", "x2", "x3", "x5", "x7", "x8", "x9", "x16", "x19", "x22"})
             for (size_t b = 0; b < P.bufs.size(); ++b)
@@ -443,10 +468,27 @@ static int get_plan(obb_ctx *ctx, int h, int w, Plan **out) {
     return OBB_OK;
 }
 
-static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t st) {
+static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t main_st) {
     Model &M = *ctx->model;
+    // Opt-in (OBB_LANES=1): measured +2 % on an isolated forward, but the extra streams defeat the forward / post-processing
+    // overlap of the pipelined step loop, so the default keeps the forward on the caller's stream.
+    static const bool use_lanes = getenv("OBB_LANES") && atoi(getenv("OBB_LANES")) != 0;
+    if (use_lanes && !P.lanes[0]) {
+        for (int i = 0; i < 3; ++i) {
+            OBB_HIP(ctx, hipStreamCreateWithFlags(&P.lanes[i], hipStreamNonBlocking));
+            OBB_HIP(ctx, hipEventCreateWithFlags(&P.ev_feat[i], hipEventDisableTiming));
+            OBB_HIP(ctx, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
+        }
+    }
+    bool lane_used[3] = {false, false, false};
     for (Op &op : P.ops) {
         hipError_t e = hipSuccess;
+        hipStream_t st = main_st;
+        if (use_lanes && op.lane > 0) {
+            st = P.lanes[op.lane - 1];
+            lane_used[op.lane - 1] = true;
+            if (op.wait_feat >= 0) OBB_HIP(ctx, hipStreamWaitEvent(st, P.ev_feat[op.wait_feat], 0));
+        }
         switch (op.type) {
             case OP_CONV: {
                 ConvLaunch L = op.conv;
@@ -474,7 +516,13 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
             case OP_ATTN: e = launch_attention(tref(P, op.in), tref(P, op.out), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
+        if (use_lanes && op.signal_feat >= 0) OBB_HIP(ctx, hipEventRecord(P.ev_feat[op.signal_feat], main_st));
     }
+    for (int i = 0; i < 3; ++i)  // join: everything after this forward on the caller's stream sees the complete head
+        if (lane_used[i]) {
+            OBB_HIP(ctx, hipEventRecord(P.ev_done[i], P.lanes[i]));
+            OBB_HIP(ctx, hipStreamWaitEvent(main_st, P.ev_done[i], 0));
+        }
     return OBB_OK;
 }
 

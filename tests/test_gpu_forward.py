@@ -101,3 +101,17 @@ def test_forward_is_deterministic_and_batch_invariant(ops, net_n):
     assert torch.equal(a, b)
     c = ops.forward(t[1:3].contiguous())
     assert torch.equal(a[1:3], c)  # a tile's result does not depend on its neighbours in the batch
+
+
+def test_four_channel_and_s_scale_models(ops):
+    """config 4 network input (RGB + DT-edge: 4 channels, no BGR flip) and the wider 's' scale run through the same kernels."""
+    for scale, ch, h, w in (("n", 4, 416, 416), ("s", 3, 128, 160)):
+        m = Yolo11OBB(scale, nc=12, ch=ch, seed=3)
+        ops.model_load(m.to_blob())
+        x = np.random.default_rng(7).integers(0, 256, (2, h, w, ch), dtype=np.uint8)
+        head = ops.forward(torch.as_tensor(x).cuda()).cpu()[..., :77]
+        r16, r32 = m.forward_raw(x, "f16"), m.forward_raw(x, "fp32")
+        d16, d32, b32 = (head - r16).abs(), (head - r32).abs(), (r16 - r32).abs()
+        print(scale, ch, "vs f16 oracle", float(d16.max()), float(d16.mean()), "vs fp32", float(d32.mean()), "oracle f16-vs-fp32", float(b32.mean()))
+        assert float(d16.mean()) < 0.02 and float(d16.max()) < 1.0
+        assert float(d32.mean()) < 1.5 * float(b32.mean()) + 1e-3

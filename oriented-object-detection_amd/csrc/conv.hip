@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     constexpr int PAD = KS / 2;
     const int S = P.stride;
     const int THin = (P.TH - 1) * S + KS, TWin = (P.TW - 1) * S + KS;
-    const int PST = P.CK * 2 + 16;  // bytes per staged pixel (+16 B pad: spreads consecutive pixels over LDS banks)
+    const int PST = IN_U8 ? 16 : P.CK * 2 + 16;  // bytes per staged pixel (+16 B pad spreads consecutive pixels over LDS banks; the
+                                                 // 8-channel input layer packs pixels densely: twice the groups per CU)
     const int cpk = P.CK >> 3;
     const int nq = (KS == 3 ? 9 : 1) * cpk;
     const int in_px = THin * TWin;
@@ -159,9 +160,55 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         }
     };
 
+    // network input layer: raw uint8 pixels (3 or 4 bytes) are prefetched a tile ahead as packed words, converted by the LUT on the
+    // way into LDS (channels 3..7 of the 8-channel padded pixel stay zero)
+    constexpr int MAXU8 = IN_U8 ? 3 : 1;  // ceil(27*27 / 256) pixels per thread
+    unsigned u8pre[MAXU8];
+    unsigned u8ok = 0;  // bit k: pixel k of this thread lies inside the image
+    auto load_u8 = [&](int t) {
+        u8ok = 0;
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+        const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
+#pragma unroll
+        for (int k = 0; k < MAXU8; ++k) {
+            int pix = tid + k * 256;
+            int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
+            int ix = pix - iy * TWin;
+            int gy = iy0 + iy, gx = ix0 + ix;
+            unsigned v = 0;
+            if (pix < in_px && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
+                const uint8_t *sp = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
+                v = (unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16);
+                if (P.cin == 4) v |= (unsigned)sp[3] << 24;
+                u8ok |= 1u << k;
+            }
+            u8pre[k] = v;
+        }
+    };
+    auto store_u8 = [&]() {
+#pragma unroll
+        for (int k = 0; k < MAXU8; ++k) {
+            int pix = tid + k * 256;
+            if (pix >= in_px) continue;
+            unsigned v = u8pre[k];
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if ((u8ok >> k) & 1u) {
+                unsigned b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
+                uint32_t c0 = s_lut[P.flip_bgr ? b2 : b0], c1 = s_lut[b1], c2 = s_lut[P.flip_bgr ? b0 : b2];
+                uint32_t c3 = (P.cin == 4) ? (uint32_t)s_lut[b3] : 0u;
+                o.x = c0 | (c1 << 16);
+                o.y = c2 | (c3 << 16);
+            }
+            *reinterpret_cast<uint4 *>(smem + pix * PST) = o;
+        }
+    };
+
     if (t0 >= t1) return;
     load_w(0);
     if constexpr (!IN_U8) { plan_tile(t0); load_stage(0); }
+    else load_u8(t0);
     bool w_resident = false;
 
     for (int t = t0; t < t1; ++t) {
@@ -178,23 +225,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
             // ---- stage this channel chunk of the input tile (and, unless resident, the stage's weights) into LDS
             if (!w_resident) store_w();
             if constexpr (IN_U8) {
-                const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-                const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
-                for (int pix = tid; pix < in_px; pix += 256) {
-                    int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
-                    int ix = pix - iy * TWin;
-                    int gy = iy0 + iy, gx = ix0 + ix;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
-                        const uint8_t *s = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
-                        uint32_t c0 = s_lut[s[P.flip_bgr ? 2 : 0]], c1 = s_lut[s[1]], c2 = s_lut[s[P.flip_bgr ? 0 : 2]];
-                        uint32_t c3 = (P.cin == 4) ? (uint32_t)s_lut[s[3]] : 0u;
-                        v.x = c0 | (c1 << 16);
-                        v.y = c2 | (c3 << 16);
-                    }
-                    *reinterpret_cast<uint4 *>(smem + pix * PST) = v;
-                }
+                store_u8();
                 __syncthreads();
+                if (t + 1 < t1) load_u8(t + 1);  // next tile's pixels: the byte loads overlap this tile's MFMAs and epilogue
             } else {
                 store_stage();
                 __syncthreads();
@@ -388,7 +421,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
 
 static size_t conv_act_bytes(const ConvLaunch &L) {
     int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    size_t in_tile = (size_t)THin * TWin * (L.CK * 2 + 16);
+    size_t in_tile = (size_t)THin * TWin * (L.in_u8 ? 16 : L.CK * 2 + 16);
     size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);  // epilogue staging re-uses the input tile's LDS
     return (std::max(in_tile, out_tile) + 15) / 16 * 16;
 }

@@ -45,7 +45,10 @@ const char *obb_last_error(const obb_ctx *ctx);
 /* Engine knobs (no reference counterpart).  "precision": 16 = fp16 activation/weight storage (default; what
  * Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32 accumulation either way.  Applies to the next
  * obb_model_load.  "model_slot": index of the model that obb_model_load / obb_forward / obb_decode* address
- * (several models may live in one context, e.g. the 128 px and 416 px checkpoints of the dual-scale config). */
+ * (several models may live in one context, e.g. the 128 px and 416 px checkpoints of the dual-scale config).
+ * "fuse": 1 = run the C3k2 block of the stem and the class / angle branches of the head as LDS-resident layer chains
+ * (same rounding points, intermediates never reach HBM), 0 = one kernel per layer (default).  Applies to the next
+ * obb_model_load. */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */

@@ -41,9 +41,6 @@ struct ConvParams {
     float inv_twin, inv_tw;
 };
 
-// SiLU with the hardware exp and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp): its error is far below the 16-bit storage rounding
-__device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
-
 template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;

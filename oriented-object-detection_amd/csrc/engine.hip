@@ -14,6 +14,7 @@
 #include <tuple>
 
 #include "ctx.h"
+#include "fused.h"
 #include "nnops.h"
 
 namespace obb {
@@ -37,7 +38,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED };
 
 struct Op {
     OpType type;
@@ -46,6 +47,8 @@ struct Op {
     int H = 0, W = 0;        // input spatial dims
     int Ho = 0, Wo = 0;      // output spatial dims
     ConvLaunch conv;         // OP_CONV
+    FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
+    double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
     const float *dw_w = nullptr, *dw_b = nullptr;  // OP_DW (device)
     int act = 0;
@@ -100,6 +103,7 @@ struct Model {
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     bf16_t *lut_dev = nullptr;
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
+    bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
 };
 
@@ -279,6 +283,8 @@ struct Builder {
     void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e) {
         std::string name = "model." + std::to_string(li);
         int c = (int)(out.C * e);
+        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && fused_c3k2(name, in, H, W, out, e)) return;
+        if (err) return;
         int cat = buf(H, W, (2 + n) * c, name + ".cat");
         conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
         for (int i = 0; i < n; ++i) {
@@ -287,6 +293,188 @@ struct Builder {
             else bottleneck(name + ".m." + std::to_string(i), src, H, W, dst, 0.5);
         }
         conv(name + ".cv2", whole(cat), H, W, out);
+    }
+
+
+    // ------------------------------------------------------------------ LDS-resident chains (fused.h)
+    struct Region { int off = 0, pst = 0, w = 0; };
+    struct Chain {
+        FusedLaunch L;
+        std::vector<bf16_t> w;  // all steps' weights (16-bit), in step order
+        int lds = 0;
+        double macs = 0;
+        int alloc(int64_t bytes) { int o = lds; lds += (int)((bytes + 15) / 16 * 16); return o; }
+    };
+    static int pst_for(int C) { return C == 8 ? 16 : C * 2 + 16; }  // +16 B spreads consecutive pixels over the LDS banks
+    static int pick_tile(int n) {  // tile edge with the least padding; 13 divides every level of a 416-px tile
+        int best = 13;
+        double bw = 1e9;
+        for (int t : {13, 12, 8}) {
+            double waste = (double)((n + t - 1) / t * t) / n;
+            if (waste < bw - 1e-9) { bw = waste; best = t; }
+        }
+        return best;
+    }
+    static int ilog2i(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+    FusedStep *chain_conv(Chain &C, const std::string &name, int cin, int cout, int ks) {
+        const ConvRecord *r = rec(name);
+        if (!r || err) return nullptr;
+        if (r->g != 1 || r->c1 != cin || r->c2 != cout || r->k != ks || r->s != 1) {
+            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: shape does not match the fused graph", name.c_str());
+            return nullptr;
+        }
+        FusedStep &S = C.L.steps[C.L.nsteps++];
+        S = FusedStep();
+        S.type = FS_CONV; S.cin = cin; S.cout = cout; S.ks = ks; S.sh = ilog2i(cin / 8); S.act = r->act;
+        S.NF = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
+        S.ncb = (cout + 16 * S.NF - 1) / (16 * S.NF);
+        ConvTiling t{1, 1, 1, S.NF, cin};  // a single channel stage: k = (tap, cin) over ALL input channels
+        S.kst = conv_ksteps(ks, cin);
+        std::vector<bf16_t> pk = pack_conv_weights(r->w, cout, cin, ks, t, nullptr, 0, M.f16);
+        S.w_off = (int)(C.w.size() * 2);  // relative to the weight block; rebased onto LDS when the chain is closed
+        C.w.insert(C.w.end(), pk.begin(), pk.end());
+        std::vector<float> bias((size_t)S.ncb * 16 * S.NF + 64, 0.f);
+        for (int c = 0; c < cout; ++c) bias[c] = r->b[c];
+        S.bias = upload(bias);
+        return &S;
+    }
+    FusedStep *chain_dw(Chain &C, const std::string &name, int ch) {
+        const ConvRecord *r = rec(name);
+        if (!r || err) return nullptr;
+        if (r->g != r->c1 || r->c1 != r->c2 || r->k != 3 || r->s != 1 || r->c1 != ch) {
+            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: not a depthwise 3x3 matching the fused graph", name.c_str());
+            return nullptr;
+        }
+        FusedStep &S = C.L.steps[C.L.nsteps++];
+        S = FusedStep();
+        S.type = FS_DW; S.cin = ch; S.cout = ch; S.ks = 3; S.sh = ilog2i(ch / 8); S.act = r->act;
+        S.w_off = (int)(C.w.size() * 2);
+        for (int t = 0; t < 9; ++t)
+            for (int c = 0; c < ch; ++c) C.w.push_back(host_to_half(r->w[(size_t)c * 9 + t], M.f16));
+        std::vector<float> bias((size_t)ch + 64, 0.f);
+        for (int c = 0; c < ch; ++c) bias[c] = r->b[c];
+        S.bias = upload(bias);
+        return &S;
+    }
+    static void step_io(FusedStep *S, int oh, int ow, int halo, const Region &in, int in_y0, int in_x0, int in_c0, const Region *out, int out_y0,
+                        int out_x0, int out_c0) {
+        S->oh = oh; S->ow = ow; S->halo = halo; S->inv_ow = 1.0f / (float)ow;
+        S->in_off = in.off; S->in_pst = in.pst; S->in_w = in.w; S->in_y0 = in_y0; S->in_x0 = in_x0; S->in_cb = in_c0 * 2;
+        if (out) { S->out_off = out->off; S->out_pst = out->pst; S->out_w = out->w; S->out_y0 = out_y0; S->out_x0 = out_x0; S->out_cb = out_c0 * 2; }
+    }
+    // closes a chain: weights behind the activation regions, LDS budget check, op emission.  Returns false if it does not fit.
+    bool chain_emit(Chain &C, const std::string &name, Slice in, Slice out, int H, int W, int head_level, size_t ops_mark) {
+        while (C.w.size() % 8) C.w.push_back(0);
+        C.L.w_lds_off = C.alloc(0);
+        C.L.w_bytes = (int)(C.w.size() * 2);
+        C.lds += C.L.w_bytes;
+        if (err || C.lds > 160 * 1024) return false;
+        for (int i = 0; i < C.L.nsteps; ++i) C.L.steps[i].w_off += C.L.w_lds_off;
+        C.L.lds_bytes = C.lds;
+        C.L.wts = upload(C.w);
+        C.L.H = H; C.L.W = W; C.L.f16 = M.f16;
+        (void)ops_mark;
+        Op op;
+        op.type = OP_FUSED; op.name = name; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+        op.head_level = head_level;
+        op.fused = C.L;
+        op.macs = C.macs;
+        P.macs_per_img += C.macs;
+        P.ops.push_back(op);
+        if (out.buf >= 0) P.named[name] = out;
+        return !err;
+    }
+
+    // C3k2 with one plain Bottleneck (c3k = False, n = 1): cv1 -> m.0.cv1 -> m.0.cv2 (+shortcut) -> cv2 over [y0 | y1 | y2], all in LDS
+    bool fused_c3k2(const std::string &name, Slice in, int H, int W, Slice out, double e) {
+        const int c1 = in.C, c2 = out.C, c = (int)(c2 * e), chid = c / 2;
+        if (c1 % 8 || (c1 & (c1 - 1)) || c % 8 || (c & (c - 1)) || chid % 8 || c2 % 8) return false;
+        Chain C;
+        const int TH = pick_tile(H), TW = pick_tile(W);
+        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
+        Region X, CAT, T, OUT;
+        X.pst = pst_for(c1); X.w = w2;
+        OUT.pst = pst_for(c2); OUT.w = TW;
+        X.off = OUT.off = C.alloc(std::max((int64_t)h2 * w2 * X.pst, (int64_t)TH * TW * OUT.pst));  // the input block is dead once cv1 ran
+        CAT.pst = pst_for(3 * c); CAT.w = w2; CAT.off = C.alloc((int64_t)h2 * w2 * CAT.pst);
+        T.pst = pst_for(chid); T.w = w1; T.off = C.alloc((int64_t)h1 * w1 * T.pst);
+        int64_t w_est = (int64_t)(conv_ksteps(1, c1) * ((2 * c + 15) / 16) + conv_ksteps(3, c) * ((chid + 15) / 16) + conv_ksteps(3, chid) * ((c + 15) / 16) +
+                                  conv_ksteps(1, 3 * c) * ((c2 + 15) / 16)) * 1024;
+        if (C.lds + w_est > 80 * 1024 || (int64_t)h2 * w2 * (c1 / 8) > 6 * kFusedThreads) return false;  // worth it only with two groups per CU
+        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = c1; C.L.in_off = X.off; C.L.in_pst = X.pst;
+        FusedStep *s;
+        if (!(s = chain_conv(C, name + ".cv1", c1, 2 * c, 1))) return false;
+        step_io(s, h2, w2, 2, X, 0, 0, 0, &CAT, 0, 0, 0); s->mask = 1;
+        if (!(s = chain_conv(C, name + ".m.0.cv1", c, chid, 3))) return false;
+        step_io(s, h1, w1, 1, CAT, 0, 0, c, &T, 0, 0, 0); s->mask = 1;
+        if (!(s = chain_conv(C, name + ".m.0.cv2", chid, c, 3))) return false;
+        step_io(s, TH, TW, 0, T, 0, 0, 0, &CAT, 2, 2, 2 * c);
+        s->res_off = CAT.off; s->res_pst = CAT.pst; s->res_w = CAT.w; s->res_y0 = 2; s->res_x0 = 2; s->res_cb = c * 2;  // shortcut: + y1
+        if (!(s = chain_conv(C, name + ".cv2", 3 * c, c2, 1))) return false;
+        step_io(s, TH, TW, 0, CAT, 2, 2, 0, &OUT, 0, 0, 0);
+        FusedStep &st = C.L.steps[C.L.nsteps++];
+        st = FusedStep();
+        st.type = FS_STORE; st.cin = c2;
+        step_io(&st, TH, TW, 0, OUT, 0, 0, 0, nullptr, 0, 0, 0);
+        C.macs = (double)H * W * ((double)c1 * 2 * c + 9.0 * c * chid + 9.0 * chid * c + 3.0 * c * c2);
+        return chain_emit(C, name + ".cv2", in, out, H, W, -1, 0);
+    }
+
+    // class branch of the OBB head at one level: DWConv -> 1x1 -> DWConv -> 1x1 -> 1x1 (logits, fp32 rows of the head tensor)
+    bool fused_head_cls(const std::string &p, Slice feat, int H, int W, int c3, int level) {
+        const int cf = feat.C;
+        if (cf % 8 || (cf & (cf - 1)) || c3 % 8 || (c3 & (c3 - 1))) return false;
+        Chain C;
+        const int TH = pick_tile(H), TW = pick_tile(W);
+        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
+        Region X, D1, E1, D2, E2;
+        X.pst = pst_for(cf); X.w = w2; D1.pst = pst_for(cf); D1.w = w1; E1.pst = pst_for(c3); E1.w = w1;
+        D2.pst = pst_for(c3); D2.w = TW; E2.pst = pst_for(c3); E2.w = TW;
+        int a = C.alloc(std::max({(int64_t)h2 * w2 * X.pst, (int64_t)h1 * w1 * E1.pst, (int64_t)TH * TW * E2.pst}));
+        int b = C.alloc(std::max((int64_t)h1 * w1 * D1.pst, (int64_t)TH * TW * D2.pst));
+        X.off = E1.off = E2.off = a; D1.off = D2.off = b;
+        int64_t w_est = (int64_t)9 * cf * 2 + 9 * c3 * 2 + (int64_t)(conv_ksteps(1, cf) + conv_ksteps(1, c3)) * ((c3 + 15) / 16) * 1024 + conv_ksteps(1, c3) * 1024;
+        if (C.lds + w_est > 160 * 1024 || (int64_t)h2 * w2 * (cf / 8) > 6 * kFusedThreads) return false;
+        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = cf; C.L.in_off = X.off; C.L.in_pst = X.pst;
+        FusedStep *s;
+        if (!(s = chain_dw(C, p + ".0.0", cf))) return false;
+        step_io(s, h1, w1, 1, X, 0, 0, 0, &D1, 0, 0, 0);
+        if (!(s = chain_conv(C, p + ".0.1", cf, c3, 1))) return false;
+        step_io(s, h1, w1, 1, D1, 0, 0, 0, &E1, 0, 0, 0); s->mask = 1;
+        if (!(s = chain_dw(C, p + ".1.0", c3))) return false;
+        step_io(s, TH, TW, 0, E1, 0, 0, 0, &D2, 0, 0, 0);
+        if (!(s = chain_conv(C, p + ".1.1", c3, c3, 1))) return false;
+        step_io(s, TH, TW, 0, D2, 0, 0, 0, &E2, 0, 0, 0);
+        if (!(s = chain_conv(C, p + ".2", c3, M.nc, 1))) return false;
+        step_io(s, TH, TW, 0, E2, 0, 0, 0, nullptr, 0, 0, 0); s->to_global = 1;
+        C.macs = (double)H * W * (9.0 * cf + (double)cf * c3 + 9.0 * c3 + (double)c3 * c3 + (double)c3 * M.nc);
+        return chain_emit(C, p, feat, Slice{-2, 4 * kRegMax, M.nc}, H, W, level, 0);
+    }
+
+    // angle branch of the OBB head at one level: 3x3 -> 3x3 -> 1x1 (one logit per anchor, fp32)
+    bool fused_head_angle(const std::string &p, Slice feat, int H, int W, int c4, int level) {
+        const int cf = feat.C;
+        if (cf % 8 || (cf & (cf - 1)) || c4 % 8 || (c4 & (c4 - 1))) return false;
+        Chain C;
+        const int TH = pick_tile(H), TW = pick_tile(W);
+        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
+        Region X, U1, U2;
+        X.pst = pst_for(cf); X.w = w2; U1.pst = pst_for(c4); U1.w = w1; U2.pst = pst_for(c4); U2.w = TW;
+        X.off = U2.off = C.alloc(std::max((int64_t)h2 * w2 * X.pst, (int64_t)TH * TW * U2.pst));  // the input block is dead once the first 3x3 ran
+        U1.off = C.alloc((int64_t)h1 * w1 * U1.pst);
+        int64_t w_est = (int64_t)(conv_ksteps(3, cf) + conv_ksteps(3, c4) + conv_ksteps(1, c4)) * ((c4 + 15) / 16) * 1024;
+        if (C.lds + w_est > 80 * 1024 || (int64_t)h2 * w2 * (cf / 8) > 6 * kFusedThreads) return false;
+        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = cf; C.L.in_off = X.off; C.L.in_pst = X.pst;
+        FusedStep *s;
+        if (!(s = chain_conv(C, p + ".0", cf, c4, 3))) return false;
+        step_io(s, h1, w1, 1, X, 0, 0, 0, &U1, 0, 0, 0); s->mask = 1;
+        if (!(s = chain_conv(C, p + ".1", c4, c4, 3))) return false;
+        step_io(s, TH, TW, 0, U1, 0, 0, 0, &U2, 0, 0, 0);
+        if (!(s = chain_conv(C, p + ".2", c4, 1, 1))) return false;
+        step_io(s, TH, TW, 0, U2, 0, 0, 0, nullptr, 0, 0, 0); s->to_global = 1;
+        C.macs = (double)H * W * (9.0 * cf * c4 + 9.0 * c4 * c4 + (double)c4);
+        return chain_emit(C, p, feat, Slice{-2, 4 * kRegMax + M.nc, 1}, H, W, level, 0);
     }
 
     int build() {
@@ -390,6 +578,8 @@ struct Builder {
         for (int i = 0; i < 3; ++i) {
             size_t first_op = P.ops.size();
             std::string p = "model.23.cv3." + std::to_string(i);
+            if (M.fuse && fused_head_cls(p, whole(feats[i]), Hs[i], Ws[i], c3, i)) continue;
+            if (err) return err;
             int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1"), e1 = buf(Hs[i], Ws[i], c3, p + ".e1"), d2 = buf(Hs[i], Ws[i], c3, p + ".d2"),
                 e2 = buf(Hs[i], Ws[i], c3, p + ".e2");
             dwconv(p + ".0.0", whole(feats[i]), Hs[i], Ws[i], whole(d1));
@@ -402,6 +592,8 @@ struct Builder {
         for (int i = 0; i < 3; ++i) {
             size_t first_op = P.ops.size();
             std::string p = "model.23.cv4." + std::to_string(i);
+            if (M.fuse && fused_head_angle(p, whole(feats[i]), Hs[i], Ws[i], c4, i)) continue;
+            if (err) return err;
             int u1 = buf(Hs[i], Ws[i], c4, p + ".u1"), u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
             conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
@@ -493,6 +685,17 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
             case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
             case OP_POOL: e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_UP: e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
+            case OP_FUSED: {
+                FusedLaunch L = op.fused;
+                L.B = B;
+                L.in = tref(P, op.in, boff);
+                if (op.head_level >= 0) {
+                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
+                } else L.out = tref(P, op.out, boff);
+                e = launch_fused(L, st);
+                break;
+            }
             case OP_ATTN: e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
@@ -555,6 +758,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     int rc = parse_blob(ctx, *M);
     if (rc) return rc;
     M->f16 = ctx->opt_f16;
+    M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
@@ -570,6 +774,10 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
     if (k == "precision") {  // 16 = fp16 storage (default), 1016 = bf16 storage; takes effect at the next obb_model_load
         OBB_REQUIRE(ctx, value == 16 || value == 1016, "obb_set_option: precision must be 16 (fp16) or 1016 (bf16)");
         ctx->opt_f16 = (value == 16);
+        return OBB_OK;
+    }
+    if (k == "fuse") {  // 1 = LDS-resident layer chains (fused.hip), 0 = one kernel per layer (default; every activation observable); next obb_model_load
+        ctx->opt_fuse = value != 0;
         return OBB_OK;
     }
     if (k == "model_slot") {  // several models per context (dual-scale 128 + 416): select which one load/forward address
@@ -673,6 +881,10 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_FUSED:
+                snprintf(line, sizeof line, "fused %s steps%d tile%dx%d out%dx%d lds%d macs%.0f\n", op.name.c_str(), op.fused.nsteps, op.fused.TH, op.fused.TW,
+                         op.Ho, op.Wo, op.fused.lds_bytes, op.macs);
+                break;
             case OP_ATTN: macs = (double)op.nh * ((double)op.N * op.N * op.kd + (double)op.N * op.N * op.hd);
                 snprintf(line, sizeof line, "attn %s N%d nh%d macs%.0f\n", op.name.c_str(), op.N, op.nh, macs); break;
         }

@@ -174,10 +174,13 @@ def select_model(slot, device=None):
     _call("obb_set_option", ctx(device), b"model_slot", int(slot))
 
 
-def model_load(blob, device=None, precision="f16"):
-    """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: 16-bit storage type."""
+def model_load(blob, device=None, precision="f16", fuse=False):
+    """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: 16-bit storage type.
+    fuse=True runs the 104x104 C3k2 block and the class / angle branches of the head as LDS-resident layer chains (fused.hip)
+    instead of one kernel per layer (the default, which is currently faster and keeps every activation observable)."""
     c = ctx(device)
     _call("obb_set_option", c, b"precision", PRECISIONS[precision])
+    _call("obb_set_option", c, b"fuse", 1 if fuse else 0)
     buf = (C.c_char * len(blob)).from_buffer_copy(blob)
     _call("obb_model_load", c, buf, len(blob))
 

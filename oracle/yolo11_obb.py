@@ -270,6 +270,8 @@ class Yolo11OBB:
         attn = (q.transpose(-2, -1) @ k) * (kd ** -0.5)
         attn = attn.softmax(dim=-1)
         o = self._q((v @ attn.transpose(-2, -1)).reshape(B, C, H, W))
+        if self.taps is not None:
+            self.taps[name] = o
         o = self._apply_conv(name + ".pe", v.reshape(B, C, H, W), residual=o)  # x = attn_out + pe(v)
         return o
 

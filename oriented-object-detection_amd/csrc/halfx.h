@@ -15,6 +15,7 @@ struct HX;
 
 template <>
 struct HX<false> {  // bf16
+    typedef __bf16 elem;
     typedef __attribute__((ext_vector_type(8))) __bf16 vec8;
     static __device__ __forceinline__ float lo(uint32_t u) { return __uint_as_float(u << 16); }
     static __device__ __forceinline__ float hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -33,6 +34,7 @@ struct HX<false> {  // bf16
 
 template <>
 struct HX<true> {  // fp16
+    typedef _Float16 elem;
     typedef __attribute__((ext_vector_type(8))) _Float16 vec8;
     static __device__ __forceinline__ float one(half_bits_t b) {
         _Float16 h;

@@ -4,6 +4,8 @@
 // writes straight into the channel slice of its consumer's concat buffer.
 #include "nnops.h"
 
+#include <cstdlib>
+
 namespace obb {
 
 // ---------------------------------------------------------------- depthwise 3x3, stride 1, pad 1 (+bias, SiLU, +residual)
@@ -196,6 +198,110 @@ __global__ __launch_bounds__(256) void k_attention(TensorRef qkv, TensorRef out,
     }
 }
 
+
+// Matrix-core form for N <= 192 tokens (every tile up to 416x448): one workgroup per (tile, head), a wave owns 16-query blocks.
+//   S^T[key][query] = K Q^T     : A = K block (LDS, 80-B rows), B = Q block (straight from global), one 16x16x32 MFMA per key block;
+//                                 the lane then holds, for ITS query (lane & 15), the scores of keys 16*jb + 4*(lane >> 4) + r.
+//   softmax over keys           : registers + two cross-lane steps (lanes l, l^16, l^32, l^48 share a query), fp32, exp(x - max).
+//   O^T[d][query] = V^T P^T     : the probabilities never leave registers: they ARE the B operand, with the k index of a 32-key
+//                                 step enumerating keys in the order the lanes hold them; V is staged in LDS in that same order.
+//                                 P is split into hi + lo 16-bit parts (two MFMAs) so that no precision is lost to its rounding.
+template <bool F16>
+__global__ __launch_bounds__(256) void k_attention_mfma(TensorRef qkv, TensorRef out, int N, int nh, float scale) {
+    constexpr int KD = 32, HD = 64, MAXKB = 12;
+    typedef typename HX<F16>::vec8 hx8;
+    typedef typename HX<F16>::elem hel;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, pl = lane & 15;
+    const int nkb = (N + 15) >> 4;   // key blocks of 16
+    const int nks = (nkb + 1) >> 1;  // k-steps of 32 keys
+    char *sK = smraw;                // [nks * 32][80 B]   (64 B of key + 16 B pad: conflict-free 16-B row reads)
+    char *sV = smraw + nks * 32 * 80;  // [nks][HD / 16][64 lanes][16 B]: A-operand fragments of V^T
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const bf16_t *base = (const bf16_t *)qkv.p + (int64_t)b * qkv.bs + qkv.co;
+    for (int i = tid; i < nks * 32 * (KD / 8); i += 256) {
+        int key = i >> 2, c = i & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < N) v = *reinterpret_cast<const uint4 *>(base + (int64_t)key * qkv.cs + nh * KD + h * KD + c * 8);
+        *reinterpret_cast<uint4 *>(sK + key * 80 + c * 16) = v;
+    }
+    for (int i = tid; i < nks * 32 * (HD / 8); i += 256) {
+        int key = i >> 3, c8 = i & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);  // keys beyond N: zeros (their probability is 0, but 0 * garbage could be NaN)
+        if (key < N) v = *reinterpret_cast<const uint4 *>(base + (int64_t)key * qkv.cs + 2 * nh * KD + h * HD + c8 * 8);
+        const int st = key >> 5, j = ((key >> 4) & 1) * 4 + (key & 3), kg = (key & 15) >> 2;
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int d = c8 * 8 + e;
+            uint16_t hv = (uint16_t)(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xffffu);
+            *reinterpret_cast<uint16_t *>(sV + (((st * (HD / 16) + (d >> 4)) * 64 + kg * 16 + (d & 15)) * 16) + j * 2) = hv;
+        }
+    }
+    __syncthreads();
+    for (int qb = wave; qb < nkb; qb += 4) {
+        const int q = qb * 16 + pl;
+        const int qc = q < N ? q : N - 1;
+        const hx8 qf = *reinterpret_cast<const hx8 *>(base + (int64_t)qc * qkv.cs + h * KD + g * 8);
+        f32x4 s[MAXKB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jb = 0; jb < MAXKB; ++jb) {
+            if (jb < nkb) {
+                hx8 kf = *reinterpret_cast<const hx8 *>(sK + (jb * 16 + pl) * 80 + g * 16);
+                s[jb] = HX<F16>::mfma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {
+                s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = (jb * 16 + g * 4 + r < N) ? s[jb][r] * scale : -INFINITY;
+                s[jb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+        f32x4 acc[HD / 16];
+#pragma unroll
+        for (int db = 0; db < HD / 16; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < MAXKB / 2; ++st) {
+            if (st >= nks) break;
+            hx8 phi, plo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float p = __expf(s[2 * st + (j >> 2)][j & 3] - mx);
+                den += p;
+                hel hi = (hel)p;
+                phi[j] = hi;
+                plo[j] = (hel)(p - (float)hi);
+            }
+#pragma unroll
+            for (int db = 0; db < HD / 16; ++db) {
+                hx8 vf = *reinterpret_cast<const hx8 *>(sV + ((st * (HD / 16) + db) * 64 + lane) * 16);
+                acc[db] = HX<F16>::mfma(vf, phi, acc[db]);
+                acc[db] = HX<F16>::mfma(vf, plo, acc[db]);
+            }
+        }
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        if (q < N) {
+            const float inv = 1.0f / den;
+            bf16_t *op = (bf16_t *)out.p + (int64_t)b * out.bs + (int64_t)q * out.cs + out.co + h * HD + g * 4;
+#pragma unroll
+            for (int db = 0; db < HD / 16; ++db) {
+                uint2 o;
+                o.x = HX<F16>::pack2(acc[db][0] * inv, acc[db][1] * inv);
+                o.y = HX<F16>::pack2(acc[db][2] * inv, acc[db][3] * inv);
+                *reinterpret_cast<uint2 *>(op + db * 16) = o;
+            }
+        }
+    }
+}
+
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B,
@@ -236,6 +342,15 @@ static hipError_t launch_attention_t(const TensorRef &qkv, const TensorRef &out,
 
 hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool f16, hipStream_t st) {
     if (kd != 32 || hd != 64) return hipErrorInvalidValue;  // head_dim is 64 for every YOLO11 scale (heads = c/64)
+    static const bool use_mfma = !(getenv("OBB_ATTN_MFMA") && atoi(getenv("OBB_ATTN_MFMA")) == 0);
+    if (use_mfma && N <= 192 && N >= 1) {
+        const int nks = ((N + 15) / 16 + 1) / 2;
+        size_t lds_m = (size_t)nks * 32 * 80 + (size_t)nks * 4 * 1024;
+        float scale = (float)(1.0 / sqrt((double)kd));
+        if (f16) hipLaunchKernelGGL(k_attention_mfma<true>, dim3((unsigned)(B * nh)), dim3(256), lds_m, st, qkv, out, N, nh, scale);
+        else hipLaunchKernelGGL(k_attention_mfma<false>, dim3((unsigned)(B * nh)), dim3(256), lds_m, st, qkv, out, N, nh, scale);
+        return hipGetLastError();
+    }
     size_t lds = sizeof(float) * ((size_t)N * 32 + (size_t)N * 64);
     if (lds > 160 * 1024) return hipErrorInvalidValue;  // N <= 422 tokens (input up to 640x640)
     return f16 ? launch_attention_t<true>(qkv, out, B, N, nh, kd, lds, st) : launch_attention_t<false>(qkv, out, B, N, nh, kd, lds, st);

@@ -39,7 +39,7 @@ def test_model_info(ops, net_n):
 
 ALL_TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.3", "model.4.cv2",
             "model.5", "model.6.cv2", "model.7", "model.8.cv2", "model.9.cv1", "model.9.cv2", "model.10.cv1",
-            "model.10.m.0.attn.qkv", "model.10.m.0.attn.pe", "model.10.m.0.ffn.1", "model.10.cv2",
+            "model.10.m.0.attn.qkv", "model.10.m.0.attn", "model.10.m.0.attn.pe", "model.10.m.0.ffn.1", "model.10.cv2",
             "model.13.cv2", "model.16.cv2", "model.17", "model.19.cv2", "model.20", "model.22.cv2",
             "model.23.cv2.0.1", "model.23.cv3.0.0.0", "model.23.cv3.0.1.1", "model.23.cv4.2.1"]
 # intermediates of the LDS-resident chains never reach HBM in the default (fused) plan

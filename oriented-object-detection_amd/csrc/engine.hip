@@ -16,6 +16,7 @@
 #include "ctx.h"
 #include "fused.h"
 #include "nnops.h"
+#include "stem.h"
 
 namespace obb {
 
@@ -38,7 +39,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM };
 
 struct Op {
     OpType type;
@@ -48,6 +49,7 @@ struct Op {
     int Ho = 0, Wo = 0;      // output spatial dims
     ConvLaunch conv;         // OP_CONV
     FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
+    StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
     const float *dw_w = nullptr, *dw_b = nullptr;  // OP_DW (device)
@@ -207,6 +209,21 @@ struct Builder {
         op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.one_d = (r->k == 1);
+        static const bool stem_on = !(getenv("OBB_STEM") && atoi(getenv("OBB_STEM")) == 0);
+        if (in_u8 && stem_on && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && stem_scale_is_exact(M.f16)) {
+            op.type = OP_STEM;
+            StemLaunch &S = op.stem;
+            S.Hin = Hin; S.Win = Win; S.cin = cin; S.cout = r->c2; S.act = r->act; S.f16 = M.f16;
+            S.wpk = upload(pack_stem_weights(r->w, r->c2, cin, M.ch == 3, M.f16));
+            std::vector<float> sb(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r->c2; ++c) sb[c] = r->b[c];
+            S.bias = upload(sb);
+            op.macs = (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+            P.macs_per_img += op.macs;
+            P.ops.push_back(op);
+            P.named[name] = out;
+            return;
+        }
         ConvTiling t = plan_conv(r->k, r->s, cin, r->c2, op.Ho, op.Wo);
         if (in_u8) t.CK = 8;
         ConvLaunch &L = op.conv;
@@ -685,6 +702,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
             case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
             case OP_POOL: e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_UP: e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
+            case OP_STEM: {
+                StemLaunch L = op.stem;
+                L.B = B; L.in = tiles; L.out = tref(P, op.out, boff);
+                e = launch_stem(L, st);
+                break;
+            }
             case OP_FUSED: {
                 FusedLaunch L = op.fused;
                 L.B = B;
@@ -881,6 +904,9 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_STEM:
+                snprintf(line, sizeof line, "stem %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem.cin, op.stem.cout, op.Ho, op.Wo, 4, op.macs);
+                break;
             case OP_FUSED:
                 snprintf(line, sizeof line, "fused %s steps%d tile%dx%d out%dx%d lds%d macs%.0f\n", op.name.c_str(), op.fused.nsteps, op.fused.TH, op.fused.TW,
                          op.Ho, op.Wo, op.fused.lds_bytes, op.macs);

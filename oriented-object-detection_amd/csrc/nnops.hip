@@ -25,6 +25,30 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
     int y = (int)((pix / W4) % H);
     int b = (int)(pix / ((int64_t)W4 * H));
     const bf16_t *ip = (const bf16_t *)in.p + (int64_t)b * in.bs + in.co + c8 * 8;
+    // every load of the strip is issued before the first use: 18 activation vectors (clamped address, zeroed when outside the
+    // image: exact zeros leave the sum of the taps that exist unchanged), 9 weight vectors and the bias -> one memory latency
+    uint4 raw[3][6];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        int yy = y + ky - 1;
+        bool yok = yy >= 0 && yy < H;
+        int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int xx = x0 + k - 1;
+            bool ok = yok && xx >= 0 && xx < W;
+            int xc = min(max(xx, 0), W - 1);
+            uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yc * W + xc) * in.cs);
+            raw[ky][k] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    }
+    float wv[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 *wp = reinterpret_cast<const float4 *>(w + t * C + c8 * 8);
+        float4 w0 = wp[0], w1 = wp[1];
+        wv[t][0] = w0.x; wv[t][1] = w0.y; wv[t][2] = w0.z; wv[t][3] = w0.w; wv[t][4] = w1.x; wv[t][5] = w1.y; wv[t][6] = w1.z; wv[t][7] = w1.w;
+    }
     float acc[4][8];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -32,33 +56,15 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
         for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        int yy = y + ky - 1;
-        if (yy < 0 || yy >= H) continue;  // zero padding contributes exact zeros: skipping keeps the sum order of the taps that exist
         float win[6][8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int xx = x0 + k - 1;
-            if (xx >= 0 && xx < W) {
-                uint4 v = *reinterpret_cast<const uint4 *>(ip + ((int64_t)yy * W + xx) * in.cs);
-                unpack8<F16>(v, win[k]);
-            } else {
+        for (int k = 0; k < 6; ++k) unpack8<F16>(raw[ky][k], win[k]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) win[k][j] = 0.f;
-            }
-        }
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float4 *wp = reinterpret_cast<const float4 *>(w + (ky * 3 + kx) * C + c8 * 8);
-            float4 w0 = wp[0], w1 = wp[1];
-            float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                int xx = x0 + p + kx - 1;
-                if (xx < 0 || xx >= W) continue;  // same tap order as the scalar form: out-of-image taps are simply absent
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[p][j] += win[p + kx][j] * wv[j];
-            }
-        }
+                for (int j = 0; j < 8; ++j) acc[p][j] += win[p + kx][j] * wv[ky * 3 + kx][j];
     }
     const float4 *bp = reinterpret_cast<const float4 *>(bias + c8 * 8);
     float4 b0 = bp[0], b1 = bp[1];

@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export OBB_GRAPH=0 OBB_FWD_SPLIT=1
-for t in 1 8 32; do
-  OBB_FUSED_TPW=$t OBB_FUSED_WPE=2 OBB_FUSED_DBG=60 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fts_$t -- python3 tools/fused_timing.py run > gpurun_out/fts_$t.log 2>&1 && python3 tools/fused_timing.py report gpurun_out/fts_$t
-done
-for t in 32; do
-  OBB_FUSED_TPW=$t OBB_FUSED_WPE=2 OBB_FUSED_DBG=0 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ftf_$t -- python3 tools/fused_timing.py run > gpurun_out/ftf_$t.log 2>&1 && python3 tools/fused_timing.py report gpurun_out/ftf_$t
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/stem_test.log 2>&1; tail -5 gpurun_out/stem_test.log
+OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/layers13 -- python3 tools/layer_profile.py 256 gpurun_out/layers13 > gpurun_out/layers13.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/layers13 > gpurun_out/layers13.txt
+grep -n "stem\|model.1 \|total" gpurun_out/layers13.txt
+python3 bench.py --no-cpu-baseline | python3 -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['forward_ms'],3))"

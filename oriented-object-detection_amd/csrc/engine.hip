@@ -210,7 +210,7 @@ struct Builder {
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.one_d = (r->k == 1);
         static const bool stem_on = !(getenv("OBB_STEM") && atoi(getenv("OBB_STEM")) == 0);
-        if (in_u8 && stem_on && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && stem_scale_is_exact(M.f16)) {
+        if (in_u8 && stem_on && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && r->act && stem_scale_is_exact(M.f16)) {
             op.type = OP_STEM;
             StemLaunch &S = op.stem;
             S.Hin = Hin; S.Win = Win; S.cin = cin; S.cout = r->c2; S.act = r->act; S.f16 = M.f16;

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
 }
 
 // SiLU with the hardware exp and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp): its error is far below the 16-bit storage rounding
-__device__ __forceinline__ float silu_f(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // host-side conversions (RNE)
 inline half_bits_t host_to_bf16(float f) {

@@ -4,7 +4,8 @@
 // (Detect_OBB.py:81-83 -> OBBModel layer 0).  The generic implicit-GEMM kernel spends its time on this layer in per-tile
 // latency (13x13 tiles, byte loads, four barriers per 169 pixels); the layer itself is pure streaming: 0.5 MB of uint8 in,
 // 1.4 MB of 16-bit activations out per 416x416 tile.  Here a workgroup owns 4 output rows x the whole width:
-//   * the 9 input rows it needs are whole contiguous byte runs of the image -> 16-B loads, prefetched a stripe ahead,
+//   * the 9 input rows it needs are whole contiguous byte runs of the image: a thread owns 16 consecutive pixels (CH 16-B
+//     loads, prefetched a stripe ahead into registers),
 //   * bytes -> 16-bit v/255 (v * (1/255) rounds to the same 16-bit value as v/255 for all 256 inputs; checked by the host
 //     before this kernel is selected) into an LDS image [row][1 + W + 1][4 channels] (left / top zero padding included),
 //   * k = (dy, dx-pair, channel): the two horizontally adjacent taps of a stride-2 window are 16 contiguous LDS bytes, so a
@@ -24,26 +25,29 @@ struct StemParams {
     const uint8_t *in; int64_t in_bs;
     bf16_t *out; int64_t out_bs; int out_cs, out_co;
     const bf16_t *wpk; const float *bias;
-    int Hin, Win, Hout, Wout, act;
+    int Hin, Win, Hout, Wout;
     int stripes_y, nstripes, spw;  // stripes per image, total, per workgroup
-    int rb, cpr, nchunk;           // bytes per input row, 16-B chunks per row, chunks per stripe
-    int cvt_off, pitch;            // LDS offset of the converted image; its row pitch in bytes
-    int gpr; float inv_gpr;        // 4-pixel groups per input row
+    int rb;                        // bytes per input row
+    int pitch;                     // row pitch of the converted LDS image in bytes
+    int ipr, nitem; float inv_ipr; // 16-pixel work items per input row, per stripe (<= 256: one per thread)
     int fpr;                       // 16-pixel fragments per output row
 };
 
-constexpr int kStemRows = 4, kStemInRows = 2 * kStemRows + 1;
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }  // s_waitcnt vmcnt(n), other counters untouched (gfx9 encoding)
+constexpr int kStemRows = 4, kStemInRows = 2 * kStemRows + 1;  // 4 output rows per stripe = one per wave
 
-template <int NF, int CH, bool F16>
+// FPR > 0: fragments per output row known at compile time -> the fragment loop is fully unrolled, which lets the compiler wait for
+// the prefetched loads with an exact vmcnt (loads and stores share one in-order counter on gfx9: a loop of unknown length forces
+// vmcnt(0), i.e. a full drain of this stripe's stores before the next stripe can start) and overlap consecutive fragments.
+template <int NF, int CH, bool F16, int FPR>
 __global__ __launch_bounds__(256) void k_stem_conv(const StemParams P) {
     typedef typename HX<F16>::vec8 hx8;
-    constexpr int MAXPF = CH == 3 ? 3 : 4;  // ceil(9 rows * 416 px * CH / 16 / 256)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, pl = lane & 15;
     const int s0 = blockIdx.x * P.spw;
     const int s1 = min(s0 + P.spw, P.nstripes);
     if (s0 >= s1) return;
-    char *raw = smem, *cvt = smem + P.cvt_off;
+    char *cvt = smem;
 
     // weights: 2 k-steps x NF fragments, resident in registers; bias of the lane's 4*NF couts
     hx8 wf[2][NF];
@@ -57,51 +61,47 @@ __global__ __launch_bounds__(256) void k_stem_conv(const StemParams P) {
         float4 bv = *reinterpret_cast<const float4 *>(P.bias + g * 4 * NF + f * 4);
         bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
     }
+    // loads and stores share one in-order counter (vmcnt): settle the loop-invariant loads here, otherwise their first use inside the
+    // stripe loop would also wait for the stripe prefetch issued just before it
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
     // zero padding columns of the converted image (never overwritten): pixel index 0 (x = -1) and W + 1 (read with zero weights)
     for (int i = tid; i < kStemInRows * 2; i += 256) {
         int r = i >> 1, side = i & 1;
         *reinterpret_cast<uint2 *>(cvt + r * P.pitch + (side ? (P.Win + 1) * 8 : 0)) = make_uint2(0, 0);
     }
 
-    u32x4 pre[MAXPF];
+    // work item = 16 consecutive pixels of one input row = CH contiguous 16-B chunks; a stripe has at most 256 items, so a thread
+    // owns one item: its bytes are prefetched a stripe ahead into registers and converted straight into the LDS image
+    // (everything below is branch-free on purpose: loads, conversions and LDS writes are unconditional, so the compiler's vmcnt
+    // bookkeeping stays exact and the wait for the prefetch does not have to drain the stores issued after it)
+    const int my_r0 = (int)(((float)tid + 0.5f) * P.inv_ipr);
+    const bool mine = tid < P.nitem;
+    const int my_r = mine ? my_r0 : 0, my_k = mine ? tid - my_r0 * P.ipr : 0;
+    char *const dp = mine ? cvt + my_r * P.pitch + (1 + 16 * my_k) * 8 : cvt + kStemInRows * P.pitch;  // others: 128-B dummy slot
+    u32x4 pre[CH];
+    bool pre_ok = false;
     auto issue = [&](int s) {
         const int b = s / P.stripes_y, oy0 = (s - b * P.stripes_y) * kStemRows;
-        const uint8_t *src = P.in + (int64_t)b * P.in_bs;
+        const int gy = 2 * oy0 - 1 + my_r;
+        pre_ok = mine && gy >= 0 && gy < P.Hin;
+        const uint8_t *src = P.in + (int64_t)b * P.in_bs + (int64_t)min(max(gy, 0), P.Hin - 1) * P.rb + my_k * 16 * CH;
 #pragma unroll
-        for (int k = 0; k < MAXPF; ++k) {
-            int idx = tid + k * 256;
-            int r = idx / P.cpr, c = idx - r * P.cpr;
-            int gy = 2 * oy0 - 1 + r;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (idx < P.nchunk && gy >= 0 && gy < P.Hin) v = *reinterpret_cast<const u32x4 *>(src + (int64_t)gy * P.rb + c * 16);
-            pre[k] = v;
-        }
+        for (int k = 0; k < CH; ++k) pre[k] = *reinterpret_cast<const u32x4 *>(src + k * 16);
     };
     issue(s0);
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));  // first stripe: settled before the loop, so that inside the loop the prefetch is always "FPR stores old"
     for (int s = s0; s < s1; ++s) {
         const int b = s / P.stripes_y, oy0 = (s - b * P.stripes_y) * kStemRows;
         __syncthreads();  // the previous stripe's fragments are done with the LDS image
+        {  // ---- bytes -> 16-bit v/255 (rows outside the image: zeros)
+            unsigned bytes[CH * 16];
 #pragma unroll
-        for (int k = 0; k < MAXPF; ++k) {
-            int idx = tid + k * 256;
-            if (idx < P.nchunk) *reinterpret_cast<u32x4 *>(raw + idx * 16) = pre[k];
-        }
-        __syncthreads();
-        if (s + 1 < s1) issue(s + 1);
-        // ---- bytes -> 16-bit v/255, four pixels per work item
-        for (int i = tid; i < kStemInRows * P.gpr; i += 256) {
-            int r = (int)(((float)i + 0.5f) * P.inv_gpr);
-            int k4 = i - r * P.gpr;
-            const unsigned *sp = reinterpret_cast<const unsigned *>(raw + r * P.rb + k4 * 4 * CH);
-            unsigned bytes[CH * 4];
-#pragma unroll
-            for (int d = 0; d < CH; ++d) {
-                unsigned w = sp[d];
+            for (int d = 0; d < CH * 4; ++d) {
+                unsigned w = pre_ok ? pre[d >> 2][d & 3] : 0u;
                 bytes[d * 4 + 0] = w & 0xffu; bytes[d * 4 + 1] = (w >> 8) & 0xffu; bytes[d * 4 + 2] = (w >> 16) & 0xffu; bytes[d * 4 + 3] = w >> 24;
             }
-            char *dp = cvt + r * P.pitch + (1 + 4 * k4) * 8;
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
+            for (int px = 0; px < 16; ++px) {
                 float c0 = (float)bytes[px * CH + 0] * (1.0f / 255.0f), c1 = (float)bytes[px * CH + 1] * (1.0f / 255.0f);
                 float c2 = (float)bytes[px * CH + 2] * (1.0f / 255.0f), c3 = CH == 4 ? (float)bytes[px * CH + (CH - 1)] * (1.0f / 255.0f) : 0.f;
                 uint2 o;
@@ -111,10 +111,13 @@ __global__ __launch_bounds__(256) void k_stem_conv(const StemParams P) {
             }
         }
         __syncthreads();
-        // ---- MFMA + epilogue + store, one 16-pixel fragment at a time
-        const int nfrag = kStemRows * P.fpr;
-        for (int fr = wave; fr < nfrag; fr += 4) {
-            const int ry = fr / P.fpr, ox = (fr - ry * P.fpr) * 16 + pl;
+        issue(min(s + 1, s1 - 1));  // unconditional (the last stripe re-reads its own rows): keeps the outstanding-op count exact
+        // ---- MFMA + epilogue + store: wave w owns output row w of the stripe, one 16-pixel fragment at a time
+        const int ry = wave;
+        const int oy = oy0 + ry;
+#pragma unroll
+        for (int i = 0; i < (FPR > 0 ? FPR : P.fpr); ++i) {
+            const int ox = i * 16 + pl;
             f32x4 acc[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -127,16 +130,13 @@ __global__ __launch_bounds__(256) void k_stem_conv(const StemParams P) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f) acc[f] = HX<F16>::mfma(wf[ks][f], a, acc[f]);
             }
-            const int oy = oy0 + ry;
-            if (oy >= P.Hout) continue;
             float v[NF * 4];
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[f][r] + bias[f * 4 + r];
-                    if (P.act) x = silu_f(x);
-                    v[f * 4 + r] = x;
+                    v[f * 4 + r] = silu_f(x);
                 }
             bf16_t *op = P.out + (int64_t)b * P.out_bs + ((int64_t)oy * P.Wout + ox) * P.out_cs + P.out_co + g * 4 * NF;
             if constexpr (NF == 1) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_stem_conv(const StemParams P) {
 bool stem_supported(int cin, int cout, int ks, int stride, int Hin, int Win) {
     if (ks != 3 || stride != 2 || (cin != 3 && cin != 4)) return false;
     if (cout != 16 && cout != 32 && cout != 64) return false;
-    if (Win % 32 || Hin % 2 || Win > 416 || Win < 32) return false;
+    if (Win % 32 || Hin % 8 || Win > 416 || Win < 32) return false;  // whole stripes of 4 output rows, whole 16-pixel fragments
     return true;
 }
 
@@ -194,31 +194,35 @@ std::vector<bf16_t> pack_stem_weights(const float *w, int cout, int cin, bool fl
 
 template <int NF, int CH>
 static hipError_t launch_t(const StemLaunch &L, const StemParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    if (L.f16) hipLaunchKernelGGL((k_stem_conv<NF, CH, true>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((k_stem_conv<NF, CH, false>), grid, dim3(256), lds, st, P);
+    if (P.fpr == 13) {  // 416-px tiles
+        if (L.f16) hipLaunchKernelGGL((k_stem_conv<NF, CH, true, 13>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_stem_conv<NF, CH, false, 13>), grid, dim3(256), lds, st, P);
+    } else {
+        if (L.f16) hipLaunchKernelGGL((k_stem_conv<NF, CH, true, 0>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_stem_conv<NF, CH, false, 0>), grid, dim3(256), lds, st, P);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_stem(const StemLaunch &L, hipStream_t st) {
-    if (!stem_supported(L.cin, L.cout, 3, 2, L.Hin, L.Win)) return hipErrorInvalidValue;
+    if (!stem_supported(L.cin, L.cout, 3, 2, L.Hin, L.Win) || !L.act) return hipErrorInvalidValue;
     StemParams P;
     P.in = L.in; P.in_bs = (int64_t)L.Hin * L.Win * L.cin;
     P.out = (bf16_t *)L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
     P.wpk = L.wpk; P.bias = L.bias;
-    P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hin / 2; P.Wout = L.Win / 2; P.act = L.act;
+    P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hin / 2; P.Wout = L.Win / 2;
     P.stripes_y = (P.Hout + kStemRows - 1) / kStemRows;
     int64_t ns = (int64_t)L.B * P.stripes_y;
     if (ns <= 0 || ns >= (1ll << 31)) return hipErrorInvalidValue;
     P.nstripes = (int)ns;
-    P.rb = L.Win * L.cin; P.cpr = P.rb / 16; P.nchunk = kStemInRows * P.cpr;
-    if (P.rb % 16 || P.nchunk > (L.cin == 3 ? 3 : 4) * 256) return hipErrorInvalidValue;
-    P.cvt_off = (kStemInRows * P.rb + 15) / 16 * 16;
+    P.rb = L.Win * L.cin;
+    P.ipr = L.Win / 16; P.nitem = kStemInRows * P.ipr; P.inv_ipr = 1.0f / (float)P.ipr;
+    if (P.rb % 16 || P.nitem > 256) return hipErrorInvalidValue;
     P.pitch = (L.Win + 2) * 8;
-    P.gpr = L.Win / 4; P.inv_gpr = 1.0f / (float)P.gpr;
     P.fpr = P.Wout / 16;
-    size_t lds = (size_t)P.cvt_off + (size_t)kStemInRows * P.pitch;
+    size_t lds = (size_t)kStemInRows * P.pitch + 128;  // + dummy slot written by threads without a work item
     static const int spw_max = getenv("OBB_STEM_SPW") ? std::max(1, atoi(getenv("OBB_STEM_SPW"))) : 4;
-    int64_t spw = ns / (256 * 3 * 2);
+    int64_t spw = ns / (256 * 5 * 2);
     P.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, spw_max));
     dim3 grid((unsigned)((ns + P.spw - 1) / P.spw));
     const int NF = L.cout / 16;

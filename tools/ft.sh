@@ -1,7 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/stem_test.log 2>&1; tail -5 gpurun_out/stem_test.log
-OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/layers13 -- python3 tools/layer_profile.py 256 gpurun_out/layers13 > gpurun_out/layers13.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/layers13 > gpurun_out/layers13.txt
-grep -n "stem\|model.1 \|total" gpurun_out/layers13.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/stem_test.log 2>&1; tail -3 gpurun_out/stem_test.log
+OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/sf -- python3 tools/layer_profile.py 256 gpurun_out/sf > gpurun_out/sf.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/sf > gpurun_out/sf.txt; grep "stem\|total" gpurun_out/sf.txt | cut -c1-40
 python3 bench.py --no-cpu-baseline | python3 -c "
 import sys,json
 for l in sys.stdin:

@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     const int cb = blockIdx.y;
     char *wlds = smem + P.act_bytes;
     if constexpr (IN_U8) s_lut[tid] = P.lut[tid];
+    // bias of this group's 16*NF couts, kept in LDS: reading it in the epilogue must not touch vmcnt (loads and stores share that one
+    // in-order counter: a global load there would also wait for the next tile's prefetch issued before it)
+    __shared__ __attribute__((aligned(16))) float s_bias[16 * NF];
+    if (tid < 16 * NF) s_bias[tid] = P.bias[blockIdx.y * 16 * NF + tid];
 
     // ---- tile-independent per-lane state
     int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (ty << 16 | tx) or -1
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         float bias[NF * 4];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase + f * 4);
+            float4 bv = *reinterpret_cast<const float4 *>(s_bias + g * 4 * NF + f * 4);
             bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
         }
         if constexpr (!OUT_F32) __syncthreads();  // every wave is done reading the input tile: its LDS becomes the output staging area

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/stem_test.log 2>&1; tail -3 gpurun_out/stem_test.log
-OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/sf -- python3 tools/layer_profile.py 256 gpurun_out/sf > gpurun_out/sf.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/sf > gpurun_out/sf.txt; grep "stem\|total" gpurun_out/sf.txt | cut -c1-40
+timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
+OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/sg -- python3 tools/layer_profile.py 256 gpurun_out/sg > gpurun_out/sg.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/sg > gpurun_out/sg.txt; grep "total" gpurun_out/sg.txt | cut -c1-40
 python3 bench.py --no-cpu-baseline | python3 -c "
 import sys,json
 for l in sys.stdin:

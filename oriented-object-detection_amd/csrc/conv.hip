@@ -420,14 +420,23 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
     return out;
 }
 
+static bool conv_multi_stage(const ConvLaunch &L) { return (L.in_u8 ? 8 : L.cin) > L.CK; }
+
+// LDS layout: [input tile (one channel stage) | weights of the stage].  The epilogue's output staging starts at offset 0; for
+// multi-stage layers it may run over the weights as well (they are re-staged at every stage anyway), single-stage layers keep
+// their weights resident across tiles, so there the staging area must fit in front of them.
 static size_t conv_act_bytes(const ConvLaunch &L) {
     int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
     size_t in_tile = (size_t)THin * TWin * (L.in_u8 ? 16 : L.CK * 2 + 16);
-    size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);  // epilogue staging re-uses the input tile's LDS
-    return (std::max(in_tile, out_tile) + 15) / 16 * 16;
+    size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);
+    size_t a = conv_multi_stage(L) ? in_tile : std::max(in_tile, out_tile);
+    return (a + 15) / 16 * 16;
 }
 
-size_t conv_lds_bytes(const ConvLaunch &L) { return conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024; }
+size_t conv_lds_bytes(const ConvLaunch &L) {
+    size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);
+    return std::max(conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024, out_tile);
+}
 
 template <int KS, int MF, int NF, bool F16>
 static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {

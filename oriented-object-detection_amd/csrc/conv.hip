@@ -36,6 +36,7 @@ struct ConvParams {
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw, act_bytes;
     int tpw, ntiles;  // consecutive pixel tiles per workgroup; total pixel tiles (batch included)
+    int gx, ncb;      // workgroups along the tile axis; cout blocks
     unsigned in_span_bytes, w_bytes;  // buffer-descriptor ranges: bytes of one image's input slice span; bytes of the packed weights
     int dbg;  // timing experiments only (OBB_CONV_DBG): 1 skip MFMA loop, 2 skip activation loads, 4 skip SiLU, 8 skip stores, 16 skip weight loads
     float inv_twin, inv_tw;
@@ -57,13 +58,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     const int nq = (KS == 3 ? 9 : 1) * cpk;
     const int in_px = THin * TWin;
     const int nchunk = in_px << P.sh;
-    const int cb = blockIdx.y;
+    // XCD-aware launch order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The groups that compute
+    // different cout blocks of the SAME pixel tiles read the same input: they are made consecutive on one XCD, so the second and
+    // later readers hit that XCD's L2 instead of fetching the tile from HBM once per cout block.
+    const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+    const int cb = lin % P.ncb;
+    const int bx = (lin / P.ncb) * 8 + xcd;
+    if (bx >= P.gx) return;
     char *wlds = smem + P.act_bytes;
     if constexpr (IN_U8) s_lut[tid] = P.lut[tid];
     // bias of this group's 16*NF couts, kept in LDS: reading it in the epilogue must not touch vmcnt (loads and stores share that one
     // in-order counter: a global load there would also wait for the next tile's prefetch issued before it)
     __shared__ __attribute__((aligned(16))) float s_bias[16 * NF];
-    if (tid < 16 * NF) s_bias[tid] = P.bias[blockIdx.y * 16 * NF + tid];
+    if (tid < 16 * NF) s_bias[tid] = P.bias[cb * 16 * NF + tid];
 
     // ---- tile-independent per-lane state
     int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (ty << 16 | tx) or -1
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
 
     // ---- tile bookkeeping: a group walks `tpw` consecutive pixel tiles so that prologue, weight staging (single-stage layers)
     //      and the first activation fetch of the next tile are amortised / overlapped
-    const int t0 = blockIdx.x * P.tpw;
+    const int t0 = bx * P.tpw;
     const int t1 = min(t0 + P.tpw, P.ntiles);
     auto tile_origin = [&](int t, int &b, int &oy0, int &ox0) {
         int tx_i = t % P.tiles_x;
@@ -504,7 +511,8 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     static const int tpw_max = getenv("OBB_TPW") ? atoi(getenv("OBB_TPW")) : 8;
     int64_t tpw = ntiles * ncb / (256 * 8);
     P.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(tpw, tpw_max));
-    dim3 grid((unsigned)((ntiles + P.tpw - 1) / P.tpw), (unsigned)ncb);
+    P.gx = (int)((ntiles + P.tpw - 1) / P.tpw); P.ncb = ncb;
+    dim3 grid((unsigned)((P.gx + 7) / 8 * 8 * ncb));  // 1-D: see the XCD-aware decoding at the top of the kernel
     size_t lds = conv_lds_bytes(L);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (L.ks == 3) {

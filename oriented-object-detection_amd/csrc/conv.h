@@ -14,11 +14,16 @@ typedef half_bits_t bf16_t;  // raw 16-bit storage (fp16 or bf16, see halfx.h)
 // One fused conv launch: out[b, oy, ox, co] = epilogue( sum_{ky,kx,ci} in[b, oy*s+ky-p, ox*s+kx-p, ci] * W[co][ci][ky][kx] )
 // epilogue: + bias -> SiLU (optional) -> + residual (optional) -> bf16 (or fp32) store into a channel slice of `out`.
 // Tensors are NHWC slices: element (b, y, x, c) of X lives at X.p + b*X.bs + (y*W + x)*X.cs + X.co + c.
+// Channel-blocked variant (cpb > 0): the buffer is [C / blk][image][pixel][blk] with blk = 8 * cpb channels per block, so that a
+// consumer which walks the channels in stages (or reads a channel slice) touches dense memory instead of 16..32-byte pieces of wide
+// pixel rows: element (b, y, x, c) lives at X.p + (c / blk) * X.ps + b * X.bs + (y*W + x) * blk + c % blk   (co must be a multiple of blk).
 struct TensorRef {
     void *p = nullptr;
     int64_t bs = 0;  // batch stride (elements)
-    int cs = 0;      // pixel stride = channels of the underlying buffer (elements)
+    int cs = 0;      // pixel stride = channels of the underlying buffer (elements); blk for a blocked buffer
     int co = 0;      // channel offset of the slice
+    int cpb = 0;     // 16-byte chunks (8 channels) per block; 0 = plain NHWC
+    int64_t ps = 0;  // block stride (elements), blocked buffers only
 };
 
 struct ConvLaunch {

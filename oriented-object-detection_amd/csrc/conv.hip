@@ -32,6 +32,11 @@ struct ConvParams {
     const void *in; int64_t in_bs; int in_cs, in_co;
     void *out; int64_t out_bs; int out_cs, out_co;
     const bf16_t *res; int64_t res_bs; int res_cs, res_co;
+    // channel-blocked addressing (TensorRef::cpb): chunk cc of a pixel lives at (cc >> bsh) * ps + pixel * pp + (cc & bmask) * 8 elements;
+    // plain NHWC is the degenerate case bsh = 31, bmask = ~0, pp = cs
+    int in_bsh, in_bmask; unsigned in_ps2 /*bytes*/;
+    int out_bsh, out_bmask; int64_t out_ps;
+    int res_bsh, res_bmask; int64_t res_ps;
     const bf16_t *wpk; const float *bias; const bf16_t *lut;
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw, act_bytes;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         for (int k = 0; k < MAXLD; ++k) {
             int gy = iy0 + (ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
             bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
-            goff[k] = ok ? (unsigned)((((int64_t)gy * P.Win + gx) * P.in_cs + ((tid + k * 256) & (cpk - 1)) * 8) * 2) : NOPIX;
+            goff[k] = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) : NOPIX;  // pixel part; the chunk part is added per stage
         }
     };
     u32x4 pre[MAXLD];
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         for (int k = 0; k < MAXLD; ++k) {
             int c8 = (tid + k * 256) & (cpk - 1);
             unsigned off = (c8 * 8 < crem && !(P.dbg & 2)) ? goff[k] : NOPIX;
-            off = off == NOPIX ? NOPIX : off + stage * P.CK * 2;
+            const int cc = stage * cpk + c8;  // chunk index inside the input slice
+            off = off == NOPIX ? NOPIX : off + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u;
             pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
         }
     };
@@ -297,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
                     v[f * 4 + r] = x;
                 }
             if (P.res) {
-                const bf16_t *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + cbase;
+                const bf16_t *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + (int64_t)((cbase >> 3) >> P.res_bsh) * P.res_ps +
+                                   (((cbase >> 3) & P.res_bmask) << 3) + (cbase & 7);
                 if (full) {
 #pragma unroll
                     for (int h = 0; h < NF / 2 + (NF == 1); ++h) {
@@ -354,15 +361,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
             // coalesced write-out: consecutive lanes store consecutive 16-B pieces of a pixel's 32*NF-byte output row
             constexpr int CPP = 2 * NF;  // 16-B chunks per pixel
             const int npx = P.TH * P.TW;
-            bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + cb * 16 * NF;
+            bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co;
             for (int i = tid; i < npx * CPP && !(P.dbg & 8); i += 256) {
                 int p = i / CPP, ch = i - p * CPP;
-                int ty = (int)(((float)p + 0.5f) * P.inv_tw);
-                int tx = p - ty * P.TW;
+                int ty = (int)(((float)p + 0.5f) * P.inv_tw);                int tx = p - ty * P.TW;
                 if (oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
-                if (cb * 16 * NF + ch * 8 + 8 > P.cout) continue;  // cout tail of the last block (cout is a multiple of 8)
+                const int occ = cb * 2 * NF + ch;           // 8-channel chunk index inside the output slice
+                if (occ * 8 + 8 > P.cout) continue;        // cout tail of the last block (cout is a multiple of 8)
                 uint4 o = *reinterpret_cast<const uint4 *>(smem + p * ROWB + ch * 16);
-                *reinterpret_cast<uint4 *>(obase + ((int64_t)(oy0 + ty) * P.Wout + ox0 + tx) * P.out_cs + ch * 8) = o;
+                *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((int64_t)(oy0 + ty) * P.Wout + ox0 + tx) * P.out_cs +
+                                           ((occ & P.out_bmask) << 3)) = o;
             }
         }
     }
@@ -475,6 +483,43 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
     P.out = L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
     P.res = (const bf16_t *)L.res.p; P.res_bs = L.res.bs; P.res_cs = L.res.cs; P.res_co = L.res.co;
+    P.in_bsh = P.out_bsh = P.res_bsh = 31;
+    P.in_bmask = P.out_bmask = P.res_bmask = 0x7fffffff;
+    P.in_ps2 = 0; P.out_ps = 0; P.res_ps = 0;
+    int64_t in_block_span = 0;  // blocked input: elements from the slice's first block to the end of its last block (one image)
+    {
+        auto blocked = [](const TensorRef &T, int C, int &bsh, int &bmask, int64_t &ps, int &co, int &cs, int64_t *span) -> bool {
+            if (T.cpb <= 0) return true;
+            const int blk = 8 * T.cpb;
+            if ((T.cpb & (T.cpb - 1)) || T.co % blk || T.cs != blk) return false;
+            bsh = 0;
+            while ((1 << bsh) < T.cpb) ++bsh;
+            bmask = T.cpb - 1;
+            ps = T.ps;
+            if (span) *span = (int64_t)((C + blk - 1) / blk - 1) * T.ps;
+            co = 0;  // the slice offset is a whole number of blocks: folded into the base pointer by the caller below
+            return true;
+        };
+        int64_t ps_in = 0;
+        int co_in = P.in_co, cs_in = P.in_cs;
+        if (!L.in_u8) {
+            if (!blocked(L.in, L.cin, P.in_bsh, P.in_bmask, ps_in, co_in, cs_in, &in_block_span)) return hipErrorInvalidValue;
+            if (L.in.cpb > 0) {
+                if (ps_in * 2 >= (1ll << 32)) return hipErrorInvalidValue;
+                P.in = (const bf16_t *)L.in.p + (int64_t)(L.in.co / (8 * L.in.cpb)) * L.in.ps;
+                P.in_co = 0;
+                P.in_ps2 = (unsigned)(ps_in * 2);
+            }
+        } else if (L.in.cpb > 0) return hipErrorInvalidValue;
+        int co_out = P.out_co, cs_out = P.out_cs;
+        if (!blocked(L.out, L.cout, P.out_bsh, P.out_bmask, P.out_ps, co_out, cs_out, nullptr) || (L.out.cpb > 0 && L.out_f32)) return hipErrorInvalidValue;
+        if (L.out.cpb > 0) { P.out = (bf16_t *)L.out.p + (int64_t)(L.out.co / (8 * L.out.cpb)) * L.out.ps; P.out_co = 0; }
+        int co_res = P.res_co, cs_res = P.res_cs;
+        if (L.res.p) {
+            if (!blocked(L.res, L.cout, P.res_bsh, P.res_bmask, P.res_ps, co_res, cs_res, nullptr)) return hipErrorInvalidValue;
+            if (L.res.cpb > 0) { P.res = (const bf16_t *)L.res.p + (int64_t)(L.res.co / (8 * L.res.cpb)) * L.res.ps; P.res_co = 0; }
+        }
+    }
     P.wpk = L.wpk; P.bias = L.bias; P.lut = L.lut;
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout;
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
@@ -488,6 +533,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.kst = conv_ksteps(L.ks, L.CK);
     {
         int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 2;  // from the slice's first element to the end of the image
+        if (L.in.cpb > 0) span = (in_block_span + (int64_t)L.Hin * L.Win * L.in.cs) * 2;  // ... to the end of the slice's last block
         int64_t wb = (int64_t)((L.cout + 16 * L.NF - 1) / (16 * L.NF)) * P.nstage * P.kst * L.NF * 1024;
         if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = (unsigned)span;

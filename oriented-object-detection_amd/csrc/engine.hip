@@ -31,6 +31,7 @@ struct ConvRecord {
 struct Buf {
     int H, W, C;
     bool f32;
+    int blk = 0;  // > 0: channel-blocked layout [C / blk][image][pixel][blk] (TensorRef::cpb); 0 = plain NHWC
     std::string name;
     int64_t off = 0;  // byte offset into the slab per image-capacity unit (resolved at allocation)
     void *p = nullptr;
@@ -158,9 +159,11 @@ struct Builder {
     int ch(int c) const { return make_divisible(std::min(c, M.max_ch) * (double)M.width, 8); }
     int reps(int n) const { return n > 1 ? std::max((int)std::lround(n * (double)M.depth), 1) : n; }
 
-    int buf(int H, int W, int C, const std::string &name, bool f32 = false) {
+    int buf(int H, int W, int C, const std::string &name, bool f32 = false, int blk = 0) {
         Buf b;
+        static const bool blocked_on = !(getenv("OBB_BLOCKED") && atoi(getenv("OBB_BLOCKED")) == 0);
         b.H = H; b.W = W; b.C = C; b.f32 = f32; b.name = name;
+        if (blocked_on && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
         P.bufs.push_back(b);
         return (int)P.bufs.size() - 1;
     }
@@ -300,9 +303,10 @@ struct Builder {
     void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e) {
         std::string name = "model." + std::to_string(li);
         int c = (int)(out.C * e);
-        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && fused_c3k2(name, in, H, W, out, e)) return;
+        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && !P.bufs[in.buf].blk && !(out.buf >= 0 && P.bufs[out.buf].blk) && fused_c3k2(name, in, H, W, out, e)) return;
         if (err) return;
-        int cat = buf(H, W, (2 + n) * c, name + ".cat");
+        // [y0 | y1 | y2 ...]: the bottleneck reads / writes single members of this concat -> one dense block per member
+        int cat = buf(H, W, (2 + n) * c, name + ".cat", false, use_c3k ? 0 : c);
         conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
         for (int i = 0; i < n; ++i) {
             Slice src = sub(cat, (1 + i) * c, c), dst = sub(cat, (2 + i) * c, c);
@@ -511,7 +515,7 @@ struct Builder {
         conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
         int b1 = buf(H4, W4, c128, "x1");
         conv("model.1", whole(b0), H2, W2, whole(b1));
-        int b2 = buf(H4, W4, c256, "x2");
+        int b2 = buf(H4, W4, c256, "x2", false, 16);  // consumed by a 3x3 stride-2 conv in 16-channel stages
         c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
         int b3 = buf(H8, W8, c256, "x3");
         conv("model.3", whole(b2), H4, W4, whole(b3));
@@ -649,6 +653,12 @@ static TensorRef tref(const Plan &P, const Slice &s, int boff = 0) {
     TensorRef t;
     if (s.buf < 0) return t;
     const Buf &b = P.bufs[s.buf];
+    if (b.blk > 0) {  // [C / blk][cap images][pixel][blk]
+        t.p = (char *)b.p + (int64_t)boff * b.H * b.W * b.blk * 2;
+        t.bs = (int64_t)b.H * b.W * b.blk; t.cs = b.blk; t.co = s.co;
+        t.cpb = b.blk / 8; t.ps = (int64_t)P.cap * b.H * b.W * b.blk;
+        return t;
+    }
     t.p = (char *)b.p + (int64_t)boff * b.per_img() * (b.f32 ? 4 : 2);  // sub-batch `boff` owns its own image range of every buffer
     t.bs = b.per_img(); t.cs = b.C; t.co = s.co;
     return t;
@@ -756,14 +766,14 @@ static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *
 
 template <bool F16>
 __global__ void k_half_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B,
-                                    float *__restrict__ dst) {
+                                    float *__restrict__ dst, int blk, int64_t ps) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)B * npix_per_img * C;
     if (i >= total) return;
-    int c = (int)(i % C);
+    int c = (int)(i % C) + co;
     int64_t pix = (i / C) % npix_per_img;
     int64_t b = i / ((int64_t)C * npix_per_img);
-    dst[i] = HX<F16>::one(src[b * bs + pix * cs + co + c]);
+    dst[i] = HX<F16>::one(blk > 0 ? src[(int64_t)(c / blk) * ps + b * bs + pix * blk + c % blk] : src[b * bs + pix * cs + c]);
 }
 
 }  // namespace obb
@@ -940,12 +950,14 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
     if (shape_hwc_host) { shape_hwc_host[0] = b.H; shape_hwc_host[1] = b.W; shape_hwc_host[2] = sl.C; }
     if (!out) return OBB_OK;
     OBB_REQUIRE(ctx, max_elems >= n, "obb_debug_activation: output too small (%lld < %lld)", (long long)max_elems, (long long)n);
+    const int64_t hw = (int64_t)b.H * b.W;
+    const int64_t d_bs = b.blk > 0 ? hw * b.blk : b.per_img(), d_ps = b.blk > 0 ? (int64_t)P->cap * hw * b.blk : 0;
     if (ctx->model->f16)
-        hipLaunchKernelGGL(k_half_slice_to_f32<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p,
-                           b.per_img(), b.C, sl.co, sl.C, (int64_t)b.H * b.W, B, out);
+        hipLaunchKernelGGL(k_half_slice_to_f32<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, d_bs, b.C,
+                           sl.co, sl.C, hw, B, out, b.blk, d_ps);
     else
-        hipLaunchKernelGGL(k_half_slice_to_f32<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p,
-                           b.per_img(), b.C, sl.co, sl.C, (int64_t)b.H * b.W, B, out);
+        hipLaunchKernelGGL(k_half_slice_to_f32<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, d_bs, b.C,
+                           sl.co, sl.C, hw, B, out, b.blk, d_ps);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

@@ -53,7 +53,8 @@ struct Op {
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
-    const float *dw_w = nullptr, *dw_b = nullptr;  // OP_DW (device)
+    const bf16_t *dw_w = nullptr;  // OP_DW (device): 16-bit [9][C]
+    const float *dw_b = nullptr;
     int act = 0;
     int N = 0, nh = 0, kd = 0, hd = 0;  // OP_ATTN
     int head_level = -1;     // >= 0: output goes to the caller's head tensor at this level
@@ -254,9 +255,10 @@ struct Builder {
             return;
         }
         int C = in.C;
-        std::vector<float> w((size_t)9 * C), b((size_t)C + 8, 0.f);
+        std::vector<bf16_t> w((size_t)9 * C + 8, 0);
+        std::vector<float> b((size_t)C + 8, 0.f);
         for (int c = 0; c < C; ++c) {
-            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = host_from_half(host_to_half(r->w[(size_t)c * 9 + t], M.f16), M.f16);
+            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = host_to_half(r->w[(size_t)c * 9 + t], M.f16);
             b[c] = r->b[c];
         }
         Op op;

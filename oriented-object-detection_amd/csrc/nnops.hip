@@ -9,10 +9,10 @@
 namespace obb {
 
 // ---------------------------------------------------------------- depthwise 3x3, stride 1, pad 1 (+bias, SiLU, +residual)
-// w: fp32 [9][C] (values already rounded to the storage type).  A thread owns a 1x4 strip of pixels x 8 channels: the 3x6
+// w16: 16-bit [9][C] (the weights in the storage type).  A thread owns a 1x4 strip of pixels x 8 channels: the 3x6
 // input window and the 9 weight vectors are loaded once per strip (4.5 loads per output instead of 27).
 template <bool F16>
-__global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, TensorRef res, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, TensorRef res, const bf16_t *__restrict__ w16,
                                                 const float *__restrict__ bias, int B, int H, int W, int C, int act) {
     const int c8n = C >> 3;
     const int W4 = (W + 3) >> 2;
@@ -42,13 +42,12 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
             raw[ky][k] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     }
-    float wv[9][8];
+    // weights as 16-bit values (what they were rounded to anyway): the products run as mixed-precision FMAs (v_fma_mix_f32 takes
+    // the fp16 operands directly, fp32 accumulate), so no conversion instructions are spent on either operand
+    typedef typename HX<F16>::elem hel;
+    uint4 wraw[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float4 *wp = reinterpret_cast<const float4 *>(w + t * C + c8 * 8);
-        float4 w0 = wp[0], w1 = wp[1];
-        wv[t][0] = w0.x; wv[t][1] = w0.y; wv[t][2] = w0.z; wv[t][3] = w0.w; wv[t][4] = w1.x; wv[t][5] = w1.y; wv[t][6] = w1.z; wv[t][7] = w1.w;
-    }
+    for (int t = 0; t < 9; ++t) wraw[t] = *reinterpret_cast<const uint4 *>(w16 + t * C + c8 * 8);
     float acc[4][8];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -56,15 +55,18 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
         for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        float win[6][8];
+        hel win[6][8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) unpack8<F16>(raw[ky][k], win[k]);
+        for (int k = 0; k < 6; ++k) __builtin_memcpy(win[k], &raw[ky][k], 16);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx) {
+            hel wv[8];
+            __builtin_memcpy(wv, &wraw[ky * 3 + kx], 16);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[p][j] += win[p + kx][j] * wv[ky * 3 + kx][j];
+                for (int j = 0; j < 8; ++j) acc[p][j] = __builtin_fmaf((float)win[p + kx][j], (float)wv[j], acc[p][j]);
+        }
     }
     const float4 *bp = reinterpret_cast<const float4 *>(bias + c8 * 8);
     float4 b0 = bp[0], b1 = bp[1];
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(TensorRef qkv, TensorRef
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
-hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B,
+hipError_t launch_dwconv3(const TensorRef &in, const TensorRef &out, const TensorRef &res, const bf16_t *w, const float *bias, int B,
                           int H, int W, int C, int act, bool f16, hipStream_t st) {
     if (C % 8) return hipErrorInvalidValue;
     dim3 grid(blocks_for((int64_t)B * H * ((W + 3) / 4) * (C / 8)));

@@ -47,7 +47,8 @@ const char *obb_last_error(const obb_ctx *ctx);
  * obb_model_load.  "model_slot": index of the model that obb_model_load / obb_forward / obb_decode* address
  * (several models may live in one context, e.g. the 128 px and 416 px checkpoints of the dual-scale config).
  * "fuse": 1 = run the C3k2 block of the stem and the class / angle branches of the head as LDS-resident layer chains
- * (same rounding points, intermediates never reach HBM), 0 = one kernel per layer (default).  Applies to the next
+ * (same rounding points, intermediates never reach HBM), 0 = one kernel per layer (default).  "tail": 1 = the last
+ * 1x1 conv of each head branch runs fused behind its producer (default), 0 = separate launch.  Both apply to the next
  * obb_model_load. */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 

@@ -38,6 +38,13 @@ struct ConvLaunch {
     int act = 1;
     int in_u8 = 0, out_f32 = 0, flip_bgr = 0;
     int f16 = 1;  // storage type: 1 = fp16, 0 = bf16
+    // optional fused trailing 1x1 conv without activation (the last layer of an OBB-head branch): its fp32 output rows go to tail_out,
+    // the 16-bit output of THIS layer is then never written (conv_tail_supported lists the shapes that have a kernel)
+    const bf16_t *tail_wpk = nullptr;  // pack_conv_weights(w2, tail_cout, cout, 1, {.., NF = tail_cout <= 16 ? 1 : 4, CK = cout})
+    const float *tail_bias = nullptr;  // padded to a multiple of 64 floats
+    int tail_cout = 0;
+    TensorRef tail_out;
+    int tail_out_hw = 0;
     int out_hw = 0;  // > 0: 1-D launch whose OUTPUT is split per image: pixel P -> (b = P / out_hw, P % out_hw) with out.bs
     // tiling (chosen by plan_conv)
     int TH = 1, TW = 64, MF = 1, NF = 4, CK = 32;
@@ -57,6 +64,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w_oihw, int cout, int cin, in
 
 int conv_ksteps(int ks, int CK);
 size_t conv_lds_bytes(const ConvLaunch &L);
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2);
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st);
 
 }  // namespace obb

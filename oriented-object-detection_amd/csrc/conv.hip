@@ -43,11 +43,15 @@ struct ConvParams {
     int tpw, ntiles;  // consecutive pixel tiles per workgroup; total pixel tiles (batch included)
     int gx, ncb;      // workgroups along the tile axis; cout blocks
     unsigned in_span_bytes, w_bytes;  // buffer-descriptor ranges: bytes of one image's input slice span; bytes of the packed weights
+    // fused trailing 1x1 conv (TAIL): out2[pixel][cout2] = W2 . y[pixel][0 .. 16*NF) + bias2, fp32 rows of the head tensor
+    const bf16_t *w2pk; const float *bias2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, kst2, w2_off;
     int dbg;  // timing experiments only (OBB_CONV_DBG): 1 skip MFMA loop, 2 skip activation loads, 4 skip SiLU, 8 skip stores, 16 skip weight loads
     float inv_twin, inv_tw;
 };
 
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16>
+// TAIL > 0: the layer is followed by a plain 1x1 conv (no activation) whose output goes to the head tensor: that second GEMM runs
+// on the staged 16-bit output tile while it is still in LDS (TAIL = its NF), and the intermediate tensor is never written.
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,6 +80,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     // in-order counter: a global load there would also wait for the next tile's prefetch issued before it)
     __shared__ __attribute__((aligned(16))) float s_bias[16 * NF];
     if (tid < 16 * NF) s_bias[tid] = P.bias[cb * 16 * NF + tid];
+    __shared__ __attribute__((aligned(16))) float s_bias2[TAIL > 0 ? 16 * TAIL : 4];
+    if constexpr (TAIL > 0) {
+        if (tid < 16 * TAIL) s_bias2[tid] = P.bias2[tid];
+        for (int i = tid; i < P.kst2 * TAIL * 64; i += 256)  // the tail's weight fragments stay in LDS for the whole kernel
+            *reinterpret_cast<u32x4 *>(smem + P.w2_off + i * 16) = reinterpret_cast<const u32x4 *>(P.w2pk)[i];
+    }
 
     // ---- tile-independent per-lane state
     int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (ty << 16 | tx) or -1
@@ -356,7 +366,49 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
             }
             __builtin_amdgcn_sched_barrier(0);  // one fragment at a time: keeps the epilogue's live range at 4*NF values
         }
-        if constexpr (!OUT_F32) {
+        if constexpr (TAIL > 0) {
+            __syncthreads();
+            f32x4 acc2[MF][TAIL];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int f = 0; f < TAIL; ++f) acc2[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < P.kst2; ++ks) {
+                hx8 w2[TAIL];
+#pragma unroll
+                for (int f = 0; f < TAIL; ++f) w2[f] = *reinterpret_cast<const hx8 *>(smem + P.w2_off + ((ks * TAIL + f) * 64 + lane) * 16);
+                int q = ks * 4 + g;
+                q = q < 2 * NF ? q : 2 * NF - 1;  // k = the 16*NF staged channels; padding chunks carry zero weights
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    hx8 a = *reinterpret_cast<const hx8 *>(smem + ((wave * MF + mf) * 16 + pl) * ROWB + q * 16);
+#pragma unroll
+                    for (int f = 0; f < TAIL; ++f) acc2[mf][f] = HX<F16>::mfma(w2[f], a, acc2[mf][f]);
+                }
+            }
+            const int c2base = g * 4 * TAIL;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
+                if (ptyx[mf] < 0 || oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
+                int64_t ob = b, opx = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
+                if (P.out2_hw > 0) { ob = opx / P.out2_hw; opx -= ob * P.out2_hw; }  // 1-D launch, per-image output rows
+                float *op = P.out2 + ob * P.out2_bs + opx * P.out2_cs + P.out2_co + c2base;
+#pragma unroll
+                for (int f = 0; f < TAIL; ++f) {
+                    float4 bv = *reinterpret_cast<const float4 *>(s_bias2 + c2base + f * 4);
+                    float v0 = acc2[mf][f][0] + bv.x, v1 = acc2[mf][f][1] + bv.y, v2 = acc2[mf][f][2] + bv.z, v3 = acc2[mf][f][3] + bv.w;
+                    if (c2base + f * 4 + 4 <= P.cout2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
+                        *reinterpret_cast<float4 *>(op + f * 4) = make_float4(v0, v1, v2, v3);
+                    } else {
+                        if (c2base + f * 4 + 0 < P.cout2) op[f * 4 + 0] = v0;
+                        if (c2base + f * 4 + 1 < P.cout2) op[f * 4 + 1] = v1;
+                        if (c2base + f * 4 + 2 < P.cout2) op[f * 4 + 2] = v2;
+                        if (c2base + f * 4 + 3 < P.cout2) op[f * 4 + 3] = v3;
+                    }
+                }
+            }
+        } else if constexpr (!OUT_F32) {
             __syncthreads();
             // coalesced write-out: consecutive lanes store consecutive 16-B pieces of a pixel's 32*NF-byte output row
             constexpr int CPP = 2 * NF;  // 16-B chunks per pixel
@@ -364,7 +416,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
             bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co;
             for (int i = tid; i < npx * CPP && !(P.dbg & 8); i += 256) {
                 int p = i / CPP, ch = i - p * CPP;
-                int ty = (int)(((float)p + 0.5f) * P.inv_tw);                int tx = p - ty * P.TW;
+                int ty = (int)(((float)p + 0.5f) * P.inv_tw);
+                int tx = p - ty * P.TW;
                 if (oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
                 const int occ = cb * 2 * NF + ch;           // 8-channel chunk index inside the output slice
                 if (occ * 8 + 8 > P.cout) continue;        // cout tail of the last block (cout is a multiple of 8)
@@ -448,13 +501,36 @@ static size_t conv_act_bytes(const ConvLaunch &L) {
     return (a + 15) / 16 * 16;
 }
 
-size_t conv_lds_bytes(const ConvLaunch &L) {
+static size_t conv_main_lds(const ConvLaunch &L) {
     size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);
-    return std::max(conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024, out_tile);
+    return (std::max(conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024, out_tile) + 15) / 16 * 16;
+}
+
+static int tail_nf(int cout2) { return cout2 <= 16 ? 1 : 4; }
+
+size_t conv_lds_bytes(const ConvLaunch &L) {
+    size_t t = L.tail_cout > 0 ? (size_t)conv_ksteps(1, 16 * L.NF) * tail_nf(L.tail_cout) * 1024 : 0;  // tail weights behind everything else
+    return conv_main_lds(L) + t;
+}
+
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2) {
+    if (cout1 != 16 * NF || cout2 < 1 || cout2 > 64) return false;
+    const int nf2 = tail_nf(cout2);
+    return (ks == 3 && MF == 3 && NF == 4 && nf2 == 4) || (ks == 3 && MF == 3 && NF == 1 && nf2 == 1) || (ks == 1 && MF == 2 && NF == 4 && nf2 == 1);
 }
 
 template <int KS, int MF, int NF, bool F16>
 static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.tail_cout > 0) {  // only the three shapes of the OBB head are instantiated (conv_tail_supported)
+        constexpr int T = (KS == 3 && MF == 3 && NF == 4) ? 4 : 1;
+        if constexpr ((KS == 3 && MF == 3 && (NF == 4 || NF == 1)) || (KS == 1 && MF == 2 && NF == 4)) {
+            if (L.in_u8 || L.out_f32 || tail_nf(L.tail_cout) != T) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16, T>), grid, dim3(256), lds, st, P);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (L.in_u8) {
         if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false, F16>), grid, dim3(256), lds, st, P);
         else return hipErrorInvalidValue;
@@ -527,6 +603,10 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
     static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
     P.dbg = dbg;
+    P.w2pk = L.tail_wpk; P.bias2 = L.tail_bias; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs;
+    P.out2_co = L.tail_out.co; P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.kst2 = conv_ksteps(1, 16 * L.NF);
+    P.w2_off = (int)conv_main_lds(L);
+    if (L.tail_cout > 0 && (!conv_tail_supported(L.ks, L.MF, L.NF, L.cout, L.tail_cout) || !L.tail_wpk || !L.tail_bias || !L.tail_out.p)) return hipErrorInvalidValue;
 
     int cin_eff = L.in_u8 ? 8 : L.cin;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;

@@ -108,6 +108,7 @@ struct Model {
     bf16_t *lut_dev = nullptr;
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
     bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
+    bool tail = true;  // last 1x1 conv of each head branch fused behind its producer (obb_set_option "tail")
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
 };
 
@@ -196,13 +197,25 @@ struct Builder {
     }
 
     // generic dense conv (groups == 1).  in.buf == -1 -> the uint8 network input.
+    // true if `name` (a conv whose only consumer is the plain 1x1 conv `tail_name` writing to the head tensor) can run with that
+    // 1x1 fused behind it (conv.hip TAIL kernels)
+    bool tail_ok(const std::string &name, const std::string &tail_name, int Hin, int Win) {
+        if (!M.tail) return false;
+        const ConvRecord *r = rec(name), *r2 = rec(tail_name);
+        if (!r || !r2 || err) return false;
+        if (r->g != 1 || r2->g != 1 || r2->k != 1 || r2->s != 1 || r2->act || r2->c1 != r->c2 || r->s != 1) return false;
+        int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
+        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo);
+        return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2);
+    }
+
     void conv(const std::string &name, Slice in, int Hin, int Win, Slice out, Slice res = Slice(), int head_level = -1,
-              const int *perm = nullptr) {
+              const int *perm = nullptr, const char *tail_name = nullptr) {
         const ConvRecord *r = rec(name);
         if (!r || err) return;
         bool in_u8 = in.buf < 0;
         int cin = in_u8 ? M.ch : in.C;
-        if (r->g != 1 || r->c1 != cin || r->c2 != out.C) {
+        if (r->g != 1 || r->c1 != cin || (!tail_name && r->c2 != out.C)) {
             err = set_error(ctx, OBB_ERR_FORMAT, "record %s: shape (%d->%d, g%d) does not match the graph (%d->%d)", name.c_str(), r->c1,
                             r->c2, r->g, cin, out.C);
             return;
@@ -232,7 +245,7 @@ struct Builder {
         if (in_u8) t.CK = 8;
         ConvLaunch &L = op.conv;
         L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act;
-        L.in_u8 = in_u8; L.out_f32 = head_level >= 0; L.flip_bgr = (in_u8 && M.ch == 3); L.f16 = M.f16;
+        L.in_u8 = in_u8; L.out_f32 = head_level >= 0 && !tail_name; L.flip_bgr = (in_u8 && M.ch == 3); L.f16 = M.f16;
         L.TH = t.TH; L.TW = t.TW; L.MF = t.MF; L.NF = t.NF; L.CK = t.CK;
         L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
         L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
@@ -243,6 +256,21 @@ struct Builder {
         L.bias = upload(bias);
         L.lut = M.lut_dev;
         P.macs_per_img += (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+        if (tail_name) {  // fused trailing 1x1: `out` is the head slice of the TAIL's output; this layer's own output is never written
+            const ConvRecord *r2 = rec(tail_name);
+            if (!r2 || err) return;
+            const int nf2 = r2->c2 <= 16 ? 1 : 4;
+            ConvTiling t2{1, 1, 1, nf2, r->c2};
+            L.tail_wpk = upload(pack_conv_weights(r2->w, r2->c2, r->c2, 1, t2, nullptr, 0, M.f16));
+            std::vector<float> b2(((size_t)r2->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r2->c2; ++c) b2[c] = r2->b[c];
+            L.tail_bias = upload(b2);
+            L.tail_cout = r2->c2;
+            op.name = name + "+" + tail_name;
+            P.macs_per_img += (double)op.Ho * op.Wo * r2->c2 * r->c2;
+            P.ops.push_back(op);
+            return;
+        }
         P.ops.push_back(op);
         P.named[name] = out;
     }
@@ -594,8 +622,12 @@ struct Builder {
             std::string p = "model.23.cv2." + std::to_string(i);
             int t1 = buf(Hs[i], Ws[i], c2, p + ".t1"), t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(t1));
-            conv(p + ".1", whole(t1), Hs[i], Ws[i], whole(t2));
-            conv(p + ".2", whole(t2), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i);
+            if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
+                conv(p + ".1", whole(t1), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i, nullptr, (p + ".2").c_str());
+            } else {
+                conv(p + ".1", whole(t1), Hs[i], Ws[i], whole(t2));
+                conv(p + ".2", whole(t2), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i);
+            }
             mark_branch(first_op, 1, i);
         }
         for (int i = 0; i < 3; ++i) {
@@ -608,8 +640,12 @@ struct Builder {
             dwconv(p + ".0.0", whole(feats[i]), Hs[i], Ws[i], whole(d1));
             conv(p + ".0.1", whole(d1), Hs[i], Ws[i], whole(e1));
             dwconv(p + ".1.0", whole(e1), Hs[i], Ws[i], whole(d2));
-            conv(p + ".1.1", whole(d2), Hs[i], Ws[i], whole(e2));
-            conv(p + ".2", whole(e2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i);
+            if (tail_ok(p + ".1.1", p + ".2", Hs[i], Ws[i])) {
+                conv(p + ".1.1", whole(d2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i, nullptr, (p + ".2").c_str());
+            } else {
+                conv(p + ".1.1", whole(d2), Hs[i], Ws[i], whole(e2));
+                conv(p + ".2", whole(e2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i);
+            }
             mark_branch(first_op, 2, i);
         }
         for (int i = 0; i < 3; ++i) {
@@ -619,8 +655,12 @@ struct Builder {
             if (err) return err;
             int u1 = buf(Hs[i], Ws[i], c4, p + ".u1"), u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
-            conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
-            conv(p + ".2", whole(u2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i);
+            if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
+                conv(p + ".1", whole(u1), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i, nullptr, (p + ".2").c_str());
+            } else {
+                conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
+                conv(p + ".2", whole(u2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i);
+            }
             mark_branch(first_op, 3, i);
         }
         for (const char *nm : {"x0", "x1", "x2", "x3", "x5", "x7", "x8", "x9", "x16", "x19", "x22"})
@@ -698,9 +738,16 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
                 } else L.in = tref(P, op.in, boff);
                 if (op.head_level >= 0) {
-                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
-                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
-                    if (op.one_d) L.out_hw = op.Ho * op.Wo;
+                    TensorRef hr;
+                    hr.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    hr.bs = (int64_t)P.A * P.no_pad; hr.cs = P.no_pad; hr.co = op.out.co;
+                    if (L.tail_cout > 0) {
+                        L.tail_out = hr;
+                        if (op.one_d) L.tail_out_hw = op.Ho * op.Wo;
+                    } else {
+                        L.out = hr;
+                        if (op.one_d) L.out_hw = op.Ho * op.Wo;
+                    }
                 } else L.out = tref(P, op.out, boff);
                 L.res = tref(P, op.res, boff);
                 if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
@@ -794,6 +841,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     if (rc) return rc;
     M->f16 = ctx->opt_f16;
     M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
+    M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
@@ -813,6 +861,10 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
     }
     if (k == "fuse") {  // 1 = LDS-resident layer chains (fused.hip), 0 = one kernel per layer (default; every activation observable); next obb_model_load
         ctx->opt_fuse = value != 0;
+        return OBB_OK;
+    }
+    if (k == "tail") {  // 1 = fuse the final 1x1 conv of each head branch behind its producer (default), 0 = separate launches; next obb_model_load
+        ctx->opt_tail = value != 0;
         return OBB_OK;
     }
     if (k == "model_slot") {  // several models per context (dual-scale 128 + 416): select which one load/forward address
@@ -908,6 +960,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
                 grid_x = op.one_d ? -(op.Ho * op.Wo) : L.tiles_x * L.tiles_y;  // negative: pixels per image of a 1-D launch
                 grid_y = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
                 lds = (int)conv_lds_bytes(L);
+                if (L.tail_cout > 0) macs += (double)op.Ho * op.Wo * L.tail_cout * L.cout;
                 snprintf(line, sizeof line, "%s %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d MF%d NF%d CK%d gx%d gy%d lds%d macs%.0f\n", ty,
                          op.name.c_str(), L.ks, L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.MF, L.NF, L.CK, grid_x, grid_y, lds, macs);
                 break;

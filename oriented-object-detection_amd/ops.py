@@ -174,13 +174,16 @@ def select_model(slot, device=None):
     _call("obb_set_option", ctx(device), b"model_slot", int(slot))
 
 
-def model_load(blob, device=None, precision="f16", fuse=False):
+def model_load(blob, device=None, precision="f16", fuse=False, tail=True):
     """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: 16-bit storage type.
     fuse=True runs the 104x104 C3k2 block and the class / angle branches of the head as LDS-resident layer chains (fused.hip)
-    instead of one kernel per layer (the default, which is currently faster and keeps every activation observable)."""
+    instead of one kernel per layer (the default, which is currently faster and keeps every activation observable).
+    tail=False keeps the final 1x1 conv of each head branch a separate launch (default: fused behind its producer, whose own
+    output then never reaches HBM)."""
     c = ctx(device)
     _call("obb_set_option", c, b"precision", PRECISIONS[precision])
     _call("obb_set_option", c, b"fuse", 1 if fuse else 0)
+    _call("obb_set_option", c, b"tail", 1 if tail else 0)
     buf = (C.c_char * len(blob)).from_buffer_copy(blob)
     _call("obb_model_load", c, buf, len(blob))
 

@@ -51,7 +51,7 @@ def test_layer_taps_match_bf16_oracle(ops, net_n, fuse):
     x = _tiles(1, 2, 416, 416)
     taps = {}
     net_n.forward_raw(x, net_n.prec, taps)
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, fuse=fuse)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, fuse=fuse, tail=False)  # tail fusion would swallow the .1 / .1.1 taps of the head
     plan = ops.debug_plan(416, 416)
     assert any(l.startswith("fused ") for l in plan) == fuse, plan
     head = ops.forward(torch.as_tensor(x).cuda())
@@ -82,11 +82,26 @@ def test_layer_taps_match_bf16_oracle(ops, net_n, fuse):
 
 
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
+def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
+    """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""
+    x = torch.as_tensor(_tiles(55 + h + w, B, h, w)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=False)
+    ref = ops.forward(x).clone()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=True)
+    if (h, w) == (416, 416):
+        assert any("+model.23.cv2.0.2" in l for l in ops.debug_plan(h, w))
+    got = ops.forward(x)
+    torch.cuda.synchronize()
+    d = (got[..., :77] - ref[..., :77]).abs()
+    assert float(d.max()) <= 1e-5, float(d.max())
+
+
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
 def test_fused_chains_match_layer_by_layer(ops, net_n, h, w, B):
     """The LDS-resident chains round at the same points as the one-kernel-per-layer plan: what may differ is the fp32 summation
     order inside a conv (all input channels in one k-loop instead of channel stages), i.e. rare 1-ulp flips of 16-bit values."""
     x = torch.as_tensor(_tiles(77 + h + w, B, h, w)).cuda()
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, fuse=False)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, fuse=False, tail=False)
     ref = ops.forward(x).clone()
     ref_x2 = ops.debug_activation("model.2.cv2", B, h, w).clone()
     ops.model_load(net_n.to_blob(), precision=net_n.prec, fuse=True)

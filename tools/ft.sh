@@ -1,3 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
-OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/dw2 -- python3 tools/layer_profile.py 256 gpurun_out/dw2 > gpurun_out/dw2.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/dw2 > gpurun_out/dw2.txt; grep "total\|dwconv" gpurun_out/dw2.txt | cut -c1-100
+timeout -k 10 600 python -m pytest tests/test_gpu_forward.py -x -q > gpurun_out/t.log 2>&1; tail -6 gpurun_out/t.log
+OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 tools/layer_profile.py 256 gpurun_out/tl > gpurun_out/tl.log 2>&1 && python3 tools/layer_profile.py report gpurun_out/tl > gpurun_out/tl.txt; grep "total\|+model" gpurun_out/tl.txt | cut -c1-120
+python3 bench.py --no-cpu-baseline | python3 -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['forward_ms'],3))"

@@ -38,6 +38,10 @@ struct ConvLaunch {
     int act = 1;
     int in_u8 = 0, out_f32 = 0, flip_bgr = 0;
     int f16 = 1;  // storage type: 1 = fp16, 0 = bf16
+    // 1x1 over a virtual concat (up_c > 0): input channels [0, up_c) = nearest-x2 upsample of `in` (a tensor of half the resolution),
+    // channels [up_c, cin) = `in2` (full resolution).  1-D launches only (B = 1, Hin = 1, Win = batch * up_HW pixels).
+    TensorRef in2;
+    int up_c = 0, up_W = 0, up_HW = 0;  // full-resolution width and pixels per image
     // optional fused trailing 1x1 conv without activation (the last layer of an OBB-head branch): its fp32 output rows go to tail_out,
     // the 16-bit output of THIS layer is then never written (conv_tail_supported lists the shapes that have a kernel)
     const bf16_t *tail_wpk = nullptr;  // pack_conv_weights(w2, tail_cout, cout, 1, {.., NF = tail_cout <= 16 ? 1 : 4, CK = cout})

@@ -43,6 +43,9 @@ struct ConvParams {
     int tpw, ntiles;  // consecutive pixel tiles per workgroup; total pixel tiles (batch included)
     int gx, ncb;      // workgroups along the tile axis; cout blocks
     unsigned in_span_bytes, w_bytes;  // buffer-descriptor ranges: bytes of one image's input slice span; bytes of the packed weights
+    // 1x1 over a virtual concat [nearest-x2 upsample of a low-res tensor | full-res tensor] (1-D launches only): channels [0, up_c) come
+    // from `in` (low-res NHWC slice, pixel (b, y/2, x/2)), the rest from `in2`; neither the upsampled tensor nor the concat is ever stored
+    const void *in2; int in2_cs, in2_co; unsigned in2_span_bytes; int up_c, up_W, up_HW;
     // fused trailing 1x1 conv (TAIL): out2[pixel][cout2] = W2 . y[pixel][0 .. 16*NF) + bias2, fp32 rows of the head tensor
     const bf16_t *w2pk; const float *bias2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, kst2, w2_off;
     int dbg;  // timing experiments only (OBB_CONV_DBG): 1 skip MFMA loop, 2 skip activation loads, 4 skip SiLU, 8 skip stores, 16 skip weight loads
@@ -51,7 +54,8 @@ struct ConvParams {
 
 // TAIL > 0: the layer is followed by a plain 1x1 conv (no activation) whose output goes to the head tensor: that second GEMM runs
 // on the staged 16-bit output tile while it is still in LDS (TAIL = its NF), and the intermediate tensor is never written.
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0>
+// VCAT: 1x1 over a virtual [upsample | skip] concat (ConvParams::up_c); a separate instantiation so that the plain kernels stay branch-free
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +132,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     // Activations are fetched with buffer loads (one 32-bit byte offset per chunk, descriptor in SGPRs): the descriptor's range
     // check returns zeros for any offset >= num_records, which is how zero padding and partial channel stages are expressed.
     unsigned goff[MAXLD];  // BYTE offset of each chunk at stage 0 of the tile being fetched, or NOPIX (-> zeros)
-    __amdgpu_buffer_rsrc_t in_rsrc;
+    unsigned goff2[VCAT ? MAXLD : 1];  // same for the second source of a virtual concat
+    __amdgpu_buffer_rsrc_t in_rsrc, in2_rsrc;
+    if constexpr (VCAT) in2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const bf16_t *)P.in2 + P.in2_co), 0, (int)P.in2_span_bytes, 0x00020000);
     auto plan_tile = [&](int t) {
         int b, oy0, ox0;
         tile_origin(t, b, oy0, ox0);
@@ -139,7 +145,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         for (int k = 0; k < MAXLD; ++k) {
             int gy = iy0 + (ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
             bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
-            goff[k] = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) : NOPIX;  // pixel part; the chunk part is added per stage
+            if constexpr (VCAT) {  // gx = pixel index over the whole batch at full resolution
+                const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
+                const int yy = r / P.up_W, xx = r - yy * P.up_W;
+                const int64_t sp = (int64_t)bb * (P.up_HW >> 2) + (int64_t)(yy >> 1) * (P.up_W >> 1) + (xx >> 1);
+                goff[k] = ok ? (unsigned)(sp * P.in_cs * 2) : NOPIX;
+                goff2[k] = ok ? (unsigned)((int64_t)gx * P.in2_cs * 2) : NOPIX;
+            } else {
+                goff[k] = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) : NOPIX;  // pixel part; the chunk part is added per stage
+            }
         }
     };
     u32x4 pre[MAXLD];
@@ -150,8 +164,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
             int c8 = (tid + k * 256) & (cpk - 1);
             unsigned off = (c8 * 8 < crem && !(P.dbg & 2)) ? goff[k] : NOPIX;
             const int cc = stage * cpk + c8;  // chunk index inside the input slice
-            off = off == NOPIX ? NOPIX : off + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u;
-            pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+            if constexpr (VCAT) {  // stage-uniform choice of the source (up_c is a multiple of CK); offsets selected, ONE load per chunk
+                const bool second = stage * P.CK >= P.up_c;
+                unsigned o2 = (c8 * 8 < crem) ? goff2[k] : NOPIX;
+                o2 = o2 == NOPIX ? NOPIX : o2 + (unsigned)(cc - (P.up_c >> 3)) * 16u;
+                off = off == NOPIX ? NOPIX : off + (unsigned)cc * 16u;
+                pre[k] = __builtin_amdgcn_raw_buffer_load_b128(second ? in2_rsrc : in_rsrc, second ? o2 : off, 0, 0);
+            } else {
+                off = off == NOPIX ? NOPIX : off + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u;
+                pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+            }
         }
     };
     auto store_stage = [&]() {  // registers -> LDS
@@ -531,6 +553,15 @@ static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid,
             return hipErrorInvalidValue;
         }
     }
+    if (L.up_c > 0) {  // virtual upsample-concat input: one shape (the 1x1 convs behind Upsample + Concat in the neck)
+        if constexpr (KS == 1 && MF == 2 && NF == 4) {
+            if (L.in_u8 || L.out_f32) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16, 0, true>), grid, dim3(256), lds, st, P);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (L.in_u8) {
         if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false, F16>), grid, dim3(256), lds, st, P);
         else return hipErrorInvalidValue;
@@ -603,6 +634,15 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
     static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
     P.dbg = dbg;
+    P.in2 = L.in2.p; P.in2_cs = L.in2.cs; P.in2_co = L.in2.co; P.up_c = L.up_c; P.up_W = L.up_W; P.up_HW = L.up_HW; P.in2_span_bytes = 0;
+    if (L.up_c > 0) {  // virtual [upsample | skip] concat: 1-D 1x1 launches over plain NHWC sources only
+        if (L.ks != 1 || L.in_u8 || L.B != 1 || L.Hin != 1 || L.in.cpb || L.in2.cpb || !L.in2.p || L.up_c % L.CK || L.up_c >= L.cin || (L.up_W & 1) ||
+            (L.up_HW % L.up_W) || ((L.up_HW / L.up_W) & 1) || L.Win % L.up_HW)
+            return hipErrorInvalidValue;
+        int64_t s2 = ((int64_t)L.Win * L.in2.cs - L.in2.co) * 2, s1 = ((int64_t)(L.Win / 4) * L.in.cs - L.in.co) * 2;
+        if (s1 <= 0 || s2 <= 0 || s1 >= (1ll << 32) - 65536 || s2 >= (1ll << 32) - 65536) return hipErrorInvalidValue;
+        P.in2_span_bytes = (unsigned)s2;
+    }
     P.w2pk = L.tail_wpk; P.bias2 = L.tail_bias; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs;
     P.out2_co = L.tail_out.co; P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.kst2 = conv_ksteps(1, 16 * L.NF);
     P.w2_off = (int)conv_main_lds(L);
@@ -614,6 +654,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     {
         int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 2;  // from the slice's first element to the end of the image
         if (L.in.cpb > 0) span = (in_block_span + (int64_t)L.Hin * L.Win * L.in.cs) * 2;  // ... to the end of the slice's last block
+        if (L.up_c > 0) span = ((int64_t)(L.Win / 4) * L.in.cs - L.in.co) * 2;  // the low-res source of a virtual concat
         int64_t wb = (int64_t)((L.cout + 16 * L.NF - 1) / (16 * L.NF)) * P.nstage * P.kst * L.NF * 1024;
         if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = (unsigned)span;

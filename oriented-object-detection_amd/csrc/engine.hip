@@ -31,6 +31,8 @@ struct ConvRecord {
 struct Buf {
     int H, W, C;
     bool f32;
+    bool virt = false;  // virtual concat [nearest-x2 upsample of va | vb]: never materialised, read in place by a 1x1 conv (ConvLaunch::up_c)
+    int va_buf = -1, va_co = 0, va_C = 0, vb_buf = -1, vb_co = 0, vb_C = 0;
     int blk = 0;  // > 0: channel-blocked layout [C / blk][image][pixel][blk] (TensorRef::cpb); 0 = plain NHWC
     std::string name;
     int64_t off = 0;  // byte offset into the slab per image-capacity unit (resolved at allocation)
@@ -53,6 +55,7 @@ struct Op {
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
+    bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
     const bf16_t *dw_w = nullptr;  // OP_DW (device): 16-bit [9][C]
     const float *dw_b = nullptr;
     int act = 0;
@@ -109,6 +112,7 @@ struct Model {
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
     bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
     bool tail = true;  // last 1x1 conv of each head branch fused behind its producer (obb_set_option "tail")
+    bool upfold = true; // Upsample + Concat in front of a 1x1 conv read in place (OBB_UPFOLD=0: materialise them)
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
 };
 
@@ -169,6 +173,13 @@ struct Builder {
         P.bufs.push_back(b);
         return (int)P.bufs.size() - 1;
     }
+    int vbuf(int H, int W, Slice up_src, Slice skip, const std::string &name) {
+        Buf b;
+        b.H = H; b.W = W; b.C = up_src.C + skip.C; b.f32 = false; b.name = name; b.virt = true;
+        b.va_buf = up_src.buf; b.va_co = up_src.co; b.va_C = up_src.C; b.vb_buf = skip.buf; b.vb_co = skip.co; b.vb_C = skip.C;
+        P.bufs.push_back(b);
+        return (int)P.bufs.size() - 1;
+    }
     Slice whole(int b) const { return Slice{b, 0, P.bufs[b].C}; }
     Slice sub(int b, int co, int C) const { return Slice{b, co, C}; }
 
@@ -222,6 +233,14 @@ struct Builder {
         }
         Op op;
         op.type = OP_CONV; op.name = name; op.in = in; op.out = out; op.res = res; op.head_level = head_level;
+        if (!in_u8 && P.bufs[in.buf].virt) {
+            const Buf &vb = P.bufs[in.buf];
+            if (r->k != 1 || in.co != 0 || in.C != vb.C || vb.va_C % 64 || cin < 128) {
+                err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the virtual concat '%s'", name.c_str(), vb.name.c_str());
+                return;
+            }
+            op.vin = true;
+        }
         op.H = Hin; op.W = Win;
         op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
@@ -333,7 +352,7 @@ struct Builder {
     void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e) {
         std::string name = "model." + std::to_string(li);
         int c = (int)(out.C * e);
-        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && !P.bufs[in.buf].blk && !(out.buf >= 0 && P.bufs[out.buf].blk) && fused_c3k2(name, in, H, W, out, e)) return;
+        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !(out.buf >= 0 && P.bufs[out.buf].blk) && fused_c3k2(name, in, H, W, out, e)) return;
         if (err) return;
         // [y0 | y1 | y2 ...]: the bottleneck reads / writes single members of this concat -> one dense block per member
         int cat = buf(H, W, (2 + n) * c, name + ".cat", false, use_c3k ? 0 : c);
@@ -535,11 +554,18 @@ struct Builder {
         const int c64 = ch(64), c128 = ch(128), c256 = ch(256), c512 = ch(512), c1024 = ch(1024);
         const int H2 = h / 2, W2 = w / 2, H4 = h / 4, W4 = w / 4, H8 = h / 8, W8 = w / 8, H16 = h / 16, W16 = w / 16, H32 = h / 32, W32 = w / 32;
         // concat buffers that later layers read: producers write straight into their slices
-        int cat13 = buf(H16, W16, c1024 + c512, "cat13");  // [up(x10), x6]
-        int cat16 = buf(H8, W8, c512 + c512, "cat16");     // [up(x13), x4]
+        // [up(x10), x6] and [up(x13), x4] feed 1x1 convs only: with `fold` neither Upsample nor Concat is materialised, the 1x1 reads both
+        // sources in place (4x fewer bytes for the upsampled half, no copy kernels)
+        const bool fold = M.upfold && c1024 % 64 == 0 && c512 % 64 == 0 && c1024 + c512 >= 128 && !big;
+        int cat13 = -1, cat16 = -1;
+        if (!fold) {
+            cat13 = buf(H16, W16, c1024 + c512, "cat13");  // [up(x10), x6]
+            cat16 = buf(H8, W8, c512 + c512, "cat16");     // [up(x13), x4]
+        }
         int cat19 = buf(H16, W16, c256 + c512, "cat19");   // [x17, x13]
         int cat22 = buf(H32, W32, c512 + c1024, "cat22");  // [x20, x10]
-        Slice x4 = sub(cat16, c512, c512), x6 = sub(cat13, c1024, c512), x10 = sub(cat22, c512, c1024), x13 = sub(cat19, c256, c512);
+        Slice x4 = fold ? whole(buf(H8, W8, c512, "x4")) : sub(cat16, c512, c512), x6 = fold ? whole(buf(H16, W16, c512, "x6")) : sub(cat13, c1024, c512);
+        Slice x10 = sub(cat22, c512, c1024), x13 = sub(cat19, c256, c512);
 
         int b0 = buf(H2, W2, c64, "x0");
         conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
@@ -592,9 +618,11 @@ struct Builder {
             conv(nm + ".ffn.1", whole(ff), H32, W32, bsl, bsl);      // x = x + ffn(x)
         }
         conv("model.10.cv2", whole(t10), H32, W32, x10);
-        upsample(x10, H32, W32, sub(cat13, 0, c1024));
+        if (fold) cat13 = vbuf(H16, W16, x10, x6, "cat13");
+        else upsample(x10, H32, W32, sub(cat13, 0, c1024));
         c3k2(13, whole(cat13), H16, W16, x13, n2, big, 0.5);
-        upsample(x13, H16, W16, sub(cat16, 0, c512));
+        if (fold) cat16 = vbuf(H8, W8, x13, x4, "cat16");
+        else upsample(x13, H16, W16, sub(cat16, 0, c512));
         int b16 = buf(H8, W8, c256, "x16");
         c3k2(16, whole(cat16), H8, W8, whole(b16), n2, big, 0.5);
         P.ops.back().signal_feat = 0;
@@ -677,6 +705,7 @@ static int ensure_capacity(obb_ctx *ctx, Plan &P, int B) {
     int64_t off = 0;
     for (Buf &b : P.bufs) {
         b.off = off;
+        if (b.virt) continue;
         off += ((int64_t)cap * b.per_img() * (b.f32 ? 4 : 2) + 255) / 256 * 256;
     }
     void *slab = nullptr;
@@ -736,6 +765,11 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 L.B = B;
                 if (op.in.buf == -1) {
                     L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
+                } else if (op.vin) {
+                    const Buf &vb = P.bufs[op.in.buf];
+                    L.in = tref(P, Slice{vb.va_buf, vb.va_co, vb.va_C}, boff);
+                    L.in2 = tref(P, Slice{vb.vb_buf, vb.vb_co, vb.vb_C}, boff);
+                    L.up_c = vb.va_C; L.up_W = op.W; L.up_HW = op.H * op.W;
                 } else L.in = tref(P, op.in, boff);
                 if (op.head_level >= 0) {
                     TensorRef hr;
@@ -842,6 +876,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     M->f16 = ctx->opt_f16;
     M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
     M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
+    M->upfold = !(getenv("OBB_UPFOLD") && atoi(getenv("OBB_UPFOLD")) == 0);
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);

@@ -81,6 +81,25 @@ def test_layer_taps_match_bf16_oracle(ops, net_n, fuse):
     ops.model_load(net_n.to_blob(), precision=net_n.prec)
 
 
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (64, 96, 3)])
+def test_upsample_concat_read_in_place(ops, net_n, h, w, B, monkeypatch):
+    """The 1x1 convs behind Upsample + Concat read the low-res tensor and the skip tensor directly: same operands, same k order."""
+    x = torch.as_tensor(_tiles(33 + h + w, B, h, w)).cuda()
+    monkeypatch.setenv("OBB_UPFOLD", "0")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert any(l.startswith("upsample") for l in ops.debug_plan(h, w))
+    ref = ops.forward(x).clone()
+    ref13 = ops.debug_activation("model.13.cv2", B, h, w).clone()
+    monkeypatch.delenv("OBB_UPFOLD")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert not any(l.startswith("upsample") for l in ops.debug_plan(h, w))
+    got = ops.forward(x)
+    got13 = ops.debug_activation("model.13.cv2", B, h, w)
+    torch.cuda.synchronize()
+    assert float((got13 - ref13).abs().max()) == 0.0
+    assert float((got[..., :77] - ref[..., :77]).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
 def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
     """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""

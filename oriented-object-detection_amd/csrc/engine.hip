@@ -42,7 +42,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF };
 
 struct Op {
     OpType type;
@@ -587,7 +587,13 @@ struct Builder {
         int c_ = c1024 / 2;
         int cat9 = buf(H32, W32, 4 * c_, "cat9");
         conv("model.9.cv1", whole(b8), H32, W32, sub(cat9, 0, c_));
-        for (int i = 0; i < 3; ++i) pool(sub(cat9, i * c_, c_), H32, W32, sub(cat9, (i + 1) * c_, c_));
+        static const bool sppf_one = !(getenv("OBB_SPPF_FUSE") && atoi(getenv("OBB_SPPF_FUSE")) == 0);
+        if (sppf_one && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
+            Op op; op.type = OP_SPPF; op.name = "sppf.pools"; op.in = sub(cat9, 0, c_); op.out = whole(cat9); op.H = H32; op.W = W32; op.Ho = H32; op.Wo = W32;
+            P.ops.push_back(op);
+        } else {
+            for (int i = 0; i < 3; ++i) pool(sub(cat9, i * c_, c_), H32, W32, sub(cat9, (i + 1) * c_, c_));
+        }
         int b9 = buf(H32, W32, c1024, "x9");
         conv("model.9.cv2", whole(cat9), H32, W32, whole(b9));
         // C2PSA
@@ -793,6 +799,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 break;
             }
             case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
+            case OP_SPPF: e = launch_sppf_pools(tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_POOL: e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_UP: e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
             case OP_STEM: {
@@ -1002,6 +1009,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             }
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
+            case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_STEM:

@@ -120,6 +120,43 @@ __global__ __launch_bounds__(256) void k_maxpool5(TensorRef in, TensorRef out, i
     *reinterpret_cast<uint4 *>((bf16_t *)out.p + (int64_t)b * out.bs + ((int64_t)y * W + x) * out.cs + out.co + c8 * 8) = pack8<F16>(m);
 }
 
+// ---------------------------------------------------------------- SPPF: the three chained MaxPool2d(5,1,2) in one launch
+// out slices 1..3 of the concat buffer = pool(x), pool(pool(x)), pool(pool(pool(x))).  One workgroup owns (image, 32 channels): the
+// H x W plane lives in LDS and is pooled three times in place (ping-pong), each result stored as it appears.  `cat` is the concat
+// buffer [x | y1 | y2 | y3] with C channels per member.
+template <bool F16>
+__global__ __launch_bounds__(256) void k_sppf_pools(TensorRef cat, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) uint4 sp[];  // two planes [H*W][4 chunks]
+    const int groups = C >> 5;
+    const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
+    const int n = H * W * 4;
+    bf16_t *base = (bf16_t *)cat.p + (int64_t)b * cat.bs + cat.co + cg * 32;
+    uint4 *cur = sp, *nxt = sp + n;
+    for (int i = threadIdx.x; i < n; i += 256) cur[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)(i >> 2) * cat.cs + (i & 3) * 8);
+    __syncthreads();
+    for (int pass = 1; pass <= 3; ++pass) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int pix = i >> 2, c = i & 3;
+            const int y = pix / W, x = pix - y * W;
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+            for (int yy = max(0, y - 2); yy <= min(H - 1, y + 2); ++yy)
+                for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) {
+                    float f[8];
+                    unpack8<F16>(cur[(yy * W + xx) * 4 + c], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+                }
+            uint4 o = pack8<F16>(m);
+            nxt[i] = o;
+            *reinterpret_cast<uint4 *>(base + (int64_t)pass * C + (int64_t)pix * cat.cs + c * 8) = o;
+        }
+        __syncthreads();
+        uint4 *t = cur; cur = nxt; nxt = t;
+    }
+}
+
 // ---------------------------------------------------------------- nearest-neighbour x2 upsample (pure copy)
 __global__ __launch_bounds__(256) void k_upsample2(TensorRef in, TensorRef out, int B, int H, int W, int C) {
     const int c8n = C >> 3;
@@ -326,6 +363,15 @@ hipError_t launch_maxpool5(const TensorRef &in, const TensorRef &out, int B, int
     dim3 grid(blocks_for((int64_t)B * H * W * (C / 8)));
     if (f16) hipLaunchKernelGGL(k_maxpool5<true>, grid, dim3(256), 0, st, in, out, B, H, W, C);
     else hipLaunchKernelGGL(k_maxpool5<false>, grid, dim3(256), 0, st, in, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_sppf_pools(const TensorRef &cat, int B, int H, int W, int C, bool f16, hipStream_t st) {
+    size_t lds = (size_t)H * W * 4 * 16 * 2;
+    if (C % 32 || lds > 64 * 1024 || cat.cpb) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(B * (C / 32)));
+    if (f16) hipLaunchKernelGGL(k_sppf_pools<true>, grid, dim3(256), lds, st, cat, H, W, C);
+    else hipLaunchKernelGGL(k_sppf_pools<false>, grid, dim3(256), lds, st, cat, H, W, C);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 #include <string>
 #include <tuple>
 
+#include "bneck.h"
 #include "ctx.h"
 #include "fused.h"
 #include "nnops.h"
@@ -42,7 +43,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK };
 
 struct Op {
     OpType type;
@@ -53,6 +54,7 @@ struct Op {
     ConvLaunch conv;         // OP_CONV
     FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
+    BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
     bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
@@ -112,6 +114,7 @@ struct Model {
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
     bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
     bool tail = true;  // last 1x1 conv of each head branch fused behind its producer (obb_set_option "tail")
+    bool bneck = true;  // fused Bottleneck stripes at the 104 / 52 levels (obb_set_option "tail" = 0 also disables it: every tap observable)
     bool upfold = true; // Upsample + Concat in front of a 1x1 conv read in place (OBB_UPFOLD=0: materialise them)
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
 };
@@ -329,6 +332,31 @@ struct Builder {
 
     void bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e) {
         int c_ = (int)(out.C * e);
+        const bool bneck_on = !(getenv("OBB_BNECK") && atoi(getenv("OBB_BNECK")) == 0);
+        if (bneck_on && M.bneck && in.buf >= 0 && in.buf == out.buf && P.bufs[in.buf].blk == in.C && in.C == out.C && c_ * 2 == in.C &&
+            bneck_supported(in.C, H, W)) {
+            const ConvRecord *r1 = rec(name + ".cv1"), *r2 = rec(name + ".cv2");
+            if (!r1 || !r2 || err) return;
+            if (r1->k == 3 && r2->k == 3 && r1->s == 1 && r2->s == 1 && r1->g == 1 && r2->g == 1 && r1->act && r2->act && r1->c1 == in.C &&
+                r1->c2 == c_ && r2->c1 == c_ && r2->c2 == in.C) {
+                Op op;
+                op.type = OP_BNECK; op.name = name; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+                BneckLaunch &L = op.bneck;
+                L.H = H; L.W = W; L.C = in.C; L.f16 = M.f16;
+                ConvTiling t1{1, 1, 1, 1, in.C}, t2{1, 1, 1, in.C / 16, c_};
+                L.w1pk = upload(pack_conv_weights(r1->w, c_, in.C, 3, t1, nullptr, 0, M.f16));
+                L.w2pk = upload(pack_conv_weights(r2->w, in.C, c_, 3, t2, nullptr, 0, M.f16));
+                std::vector<float> b1(128, 0.f), b2(128, 0.f);
+                for (int c = 0; c < c_; ++c) b1[c] = r1->b[c];
+                for (int c = 0; c < in.C; ++c) b2[c] = r2->b[c];
+                L.bias1 = upload(b1); L.bias2 = upload(b2);
+                op.macs = (double)H * W * 9.0 * in.C * c_ * 2;
+                P.macs_per_img += op.macs;
+                P.ops.push_back(op);
+                P.named[name + ".cv2"] = out;
+                return;
+            }
+        }
         int t = buf(H, W, c_, name + ".t");
         conv(name + ".cv1", in, H, W, whole(t));
         conv(name + ".cv2", whole(t), H, W, out, in);  // shortcut add (c1 == c2)
@@ -799,6 +827,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 break;
             }
             case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
+            case OP_BNECK: {
+                BneckLaunch L = op.bneck;
+                L.B = B; L.y1 = tref(P, op.in, boff); L.y2 = tref(P, op.out, boff);
+                e = launch_bneck(L, st);
+                break;
+            }
             case OP_SPPF: e = launch_sppf_pools(tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_POOL: e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_UP: e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
@@ -884,6 +918,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
     M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
     M->upfold = !(getenv("OBB_UPFOLD") && atoi(getenv("OBB_UPFOLD")) == 0);
+    M->bneck = M->tail;  // both swallow intermediate activations: one switch ("tail" = 0 keeps every layer observable)
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
@@ -1009,6 +1044,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             }
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
+            case OP_BNECK: snprintf(line, sizeof line, "bneck %s c%d out%dx%d rows4 macs%.0f\n", op.name.c_str(), op.bneck.C, op.Ho, op.Wo, op.macs); break;
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;

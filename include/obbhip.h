@@ -60,6 +60,11 @@ int obb_poly_iou_pairs(obb_ctx *ctx, const double *a, const double *b, int64_t m
 int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int64_t na, const double *b,
                         const int32_t *cls_b, int64_t nb, double *out, obb_stream_t s);
 
+/* Center-Hit metric (Detect_OBB.py:609-648): out[i*nq + j] = 1 iff point i (a detection centre, :159-165) lies strictly inside the
+ * valid quad j  (`poly.is_valid and poly.contains(Point(cx, cy))`, :631-634) and cls_p[i] == cls_q[j] (when both are given). */
+int obb_points_in_quads(obb_ctx *ctx, const double *pts, const int32_t *cls_p, int64_t np, const double *quads, const int32_t *cls_q,
+                        int64_t nq, uint8_t *out, obb_stream_t s);
+
 /* ------------------------------------------------------------------ S3: merge_detections  (Detect_OBB.py:176-200) */
 /* order[n] = stable descending argsort of key (Python list.sort(key=conf, reverse=True), Detect_OBB.py:183). */
 int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *order, obb_stream_t s);

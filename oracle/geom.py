@@ -41,6 +41,8 @@ def lib():
         L.ora_consensus.argtypes = [dp, ip, dp, lp, C.c_int32, C.c_double, C.c_double, C.c_double, ip]
         L.ora_center_inside.restype = C.c_int
         L.ora_center_inside.argtypes = [dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.ora_point_in_quad.restype = C.c_int
+        L.ora_point_in_quad.argtypes = [dp, C.c_double, C.c_double]
         L.ora_strike_angle.restype = C.c_double
         L.ora_strike_angle.argtypes = [dp]
         L.ora_tile_grid.restype = C.c_int64
@@ -131,6 +133,12 @@ def cross_scale_consensus_filter(dets_by_scale):
 def center_inside_safe_region(points8, crop_x0, crop_y0, crop_w, crop_h, margin_px):
     p = _d(points8)
     return bool(lib().ora_center_inside(_p(p, C.c_double), crop_x0, crop_y0, crop_w, crop_h, margin_px))
+
+
+def point_in_quad(pts8, x, y):
+    """Polygon(pts).is_valid and Polygon(pts).contains(Point(x, y))  (Detect_OBB.py:631-634)"""
+    a = _d(pts8)
+    return bool(lib().ora_point_in_quad(_p(a, C.c_double), float(x), float(y)))
 
 
 def compute_angle_from_bbox(points):

@@ -276,6 +276,27 @@ int64_t ora_consensus(const double *boxes, const int32_t *cls, const double *con
     return nout;
 }
 
+/* ------------------------------------------------------------------ Center-Hit metric  (Detect_OBB.py:609-648) */
+
+/* Shapely `Polygon(pts).is_valid and Polygon(pts).contains(Point(x, y))` restated for a 4-vertex ring: the point must lie in the
+ * INTERIOR (a point on the boundary is not contained).  Boundary: exact zero of the edge cross product inside the edge's box;
+ * interior: non-zero winding number (cross-product signs only, no division).  GEOS itself is absent offline -> parity unpinned at
+ * this boundary; pinned by known answers in tests/test_oracle_geometry.py. */
+int ora_point_in_quad(const double *p8, double x, double y) {
+    pt_t p[4], q = {x, y};
+    for (int i = 0; i < 4; ++i) { p[i].x = p8[2 * i]; p[i].y = p8[2 * i + 1]; }
+    if (!quad_valid(p) || !isfinite(x) || !isfinite(y)) return 0;
+    int wn = 0;
+    for (int i = 0; i < 4; ++i) {
+        pt_t a = p[i], b = p[(i + 1) & 3];
+        double c = cross3(a, b, q);
+        if (c == 0.0 && on_seg(a, b, q)) return 0; /* on the boundary */
+        if (a.y <= y) { if (b.y > y && c > 0.0) ++wn; }
+        else if (b.y <= y && c < 0.0) --wn;
+    }
+    return wn != 0;
+}
+
 /* ------------------------------------------------------------------ border filter + strike angle */
 
 int ora_center_inside(const double *p8, double x0, double y0, double w, double h, double margin) { /* :159-174 */

@@ -40,6 +40,24 @@ __global__ __launch_bounds__(256) void k_iou_pairs(const double *__restrict__ a,
     }
 }
 
+// out[i*nq + j] = 1 iff point i lies strictly inside the valid quad j (and their classes agree when both class arrays are given)
+__global__ __launch_bounds__(256) void k_points_in_quads(const double *__restrict__ pts, const int32_t *__restrict__ cp, int64_t np,
+                                                        const double *__restrict__ quads, const int32_t *__restrict__ cq, int64_t nq,
+                                                        uint8_t *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= np * nq) return;
+    int64_t i = t / nq, j = t - i * nq;
+    bool hit = false;
+    if (!(cp && cq) || cp[i] == cq[j]) {
+        P2 q[4];
+        for (int k = 0; k < 4; ++k) { q[k].x = quads[j * 8 + 2 * k]; q[k].y = quads[j * 8 + 2 * k + 1]; }
+        P2 c;
+        c.x = pts[i * 2]; c.y = pts[i * 2 + 1];
+        hit = point_in_quad(q, c);
+    }
+    out[t] = hit ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_iou_matrix(const double *__restrict__ a, const int32_t *__restrict__ ca, int64_t na,
                                                    const double *__restrict__ b, const int32_t *__restrict__ cb, int64_t nb,
                                                    double *__restrict__ out) {
@@ -562,6 +580,17 @@ int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int
     OBB_REQUIRE(ctx, cdiv(na, 16) <= 65535, "obb_poly_iou_matrix: na too large (%lld)", (long long)na);
     hipLaunchKernelGGL(k_iou_matrix, dim3((unsigned)cdiv(nb, 16), (unsigned)cdiv(na, 16)), dim3(256), 0, (hipStream_t)s, a,
                        cls_a, na, b, cls_b, nb, out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_points_in_quads(obb_ctx *ctx, const double *pts, const int32_t *cls_p, int64_t np, const double *quads, const int32_t *cls_q,
+                        int64_t nq, uint8_t *out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && np >= 0 && nq >= 0, "obb_points_in_quads: bad arguments");
+    if (np == 0 || nq == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, pts && quads && out, "obb_points_in_quads: NULL buffer");
+    OBB_REQUIRE(ctx, np * nq < (1ll << 40), "obb_points_in_quads: matrix too large");
+    hipLaunchKernelGGL(k_points_in_quads, dim3((unsigned)cdiv(np * nq, 256)), dim3(256), 0, (hipStream_t)s, pts, cls_p, np, quads, cls_q, nq, out);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

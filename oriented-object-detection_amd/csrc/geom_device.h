@@ -56,6 +56,21 @@ __device__ __forceinline__ bool quad_valid(const P2 *p) {
     return true;
 }
 
+// Polygon(pts).is_valid and Polygon(pts).contains(Point(x, y)) of the Center-Hit metric (Detect_OBB.py:631-634): strictly interior
+// (boundary excluded), winding number from cross-product signs only.  (The test suite checks it bit for bit against a plain-C restatement.)
+__device__ __forceinline__ bool point_in_quad(const P2 *p, P2 q) {
+    if (!quad_valid(p) || !isfinite(q.x) || !isfinite(q.y)) return false;
+    int wn = 0;
+    for (int i = 0; i < 4; ++i) {
+        P2 a = p[i], b = p[(i + 1) & 3];
+        double c = cross3(a, b, q);
+        if (c == 0.0 && on_seg(a, b, q)) return false;
+        if (a.y <= q.y) { if (b.y > q.y && c > 0.0) ++wn; }
+        else if (b.y <= q.y && c < 0.0) --wn;
+    }
+    return wn != 0;
+}
+
 __device__ __forceinline__ bool is_convex(const P2 *p, int n) {
     bool pos = false, neg = false;
     for (int i = 0; i < n; ++i) {

@@ -109,3 +109,106 @@ def evaluate_map(dets_source, gt_source, iou_list=None):
         per_iou[iou] = float(np.mean(aps)) if aps else 0.0
     return {"mAP@0.5": per_iou.get(0.5, 0.0), "mAP@[0.5:0.95]": float(np.mean([per_iou[i] for i in iou_list])) if iou_list else 0.0,
             "per_iou": per_iou}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Fusion-evaluation metrics beyond mAP.  dets: 11-tuples (x1..y4, cls, conf, angle) in pixels;
+# gts: [{"cls": int, "pts": 8 floats}].  All geometry runs on the GPU (one matrix launch per image); the greedy matching loops are
+# the reference's own sequential control flow over those matrices.
+
+def prec_rec_f1(tp, fp, fn):
+    """Detect_OBB.py:482-486"""
+    P = tp / (tp + fp + 1e-9)
+    R = tp / (tp + fn + 1e-9)
+    return P, R, 2 * P * R / (P + R + 1e-9)
+
+
+def _dev(device):
+    return device or torch.device("cuda", torch.cuda.current_device())
+
+
+def match_dets_to_gts_pixel(dets, gts, iou_thr=0.5, device=None):
+    """Detect_OBB.py:456-480: detections in LIST order (no score sort), strict `iou > best_iou`, then `best_iou >= thr` -> (TP, FP, FN)"""
+    if not dets or not gts:
+        return 0, len(dets), len(gts)
+    dev = _dev(device)
+    a = torch.tensor([list(d[:8]) for d in dets], dtype=torch.float64, device=dev)
+    b = torch.tensor([list(g["pts"]) for g in gts], dtype=torch.float64, device=dev)
+    ca = torch.tensor([int(d[8]) for d in dets], dtype=torch.int32, device=dev)
+    cb = torch.tensor([int(g["cls"]) for g in gts], dtype=torch.int32, device=dev)
+    iou = ops.poly_iou_matrix(a, b, ca, cb).cpu().numpy()  # 0 where the classes differ
+    same = ca.cpu().numpy()[:, None] == cb.cpu().numpy()[None, :]
+    used = np.zeros(len(gts), bool)
+    tp = 0
+    for i in range(len(dets)):
+        best_iou, best_j = 0.0, -1
+        row = iou[i]
+        for j in np.nonzero(same[i] & ~used)[0]:
+            if row[j] > best_iou:
+                best_iou, best_j = row[j], j
+        if best_iou >= iou_thr and best_j >= 0:
+            used[best_j] = True
+            tp += 1
+    return tp, len(dets) - tp, int((~used).sum())
+
+
+def center_hit_counts(dets, gts, device=None):
+    """body of evaluate_center_hit (:609-648) for one image -> (TP, FP, FN)"""
+    if not dets or not gts:
+        return 0, len(dets), len(gts)
+    dev = _dev(device)
+    bx = np.array([list(d[:8]) for d in dets], np.float64)
+    ctr = np.stack([(bx[:, 0] + bx[:, 2] + bx[:, 4] + bx[:, 6]) / 4.0, (bx[:, 1] + bx[:, 3] + bx[:, 5] + bx[:, 7]) / 4.0], 1)  # :159-165
+    inside = ops.points_in_quads(torch.as_tensor(ctr, device=dev), torch.tensor([list(g["pts"]) for g in gts], dtype=torch.float64, device=dev),
+                                 torch.tensor([int(d[8]) for d in dets], dtype=torch.int32, device=dev),
+                                 torch.tensor([int(g["cls"]) for g in gts], dtype=torch.int32, device=dev)).cpu().numpy().astype(bool)
+    used = np.zeros(len(gts), bool)
+    tp = fp = 0
+    for i in range(len(dets)):
+        cand = np.nonzero(inside[i] & ~used)[0]
+        if len(cand):  # first unused, same-class, valid GT polygon that contains the centre
+            used[cand[0]] = True
+            tp += 1
+        else:
+            fp += 1
+    return tp, fp, int((~used).sum())
+
+
+def evaluate_center_hit(dets_source, gt_source, conf_thr=0.5, device=None):
+    """-> (P, R, F1, TP, FP, FN)"""
+    tp = fp = fn = 0
+    for img, gts in gt_source.items():
+        dets = [d for d in dets_source.get(img, []) if d[9] >= conf_thr]
+        a, b, c = center_hit_counts(dets, gts, device)
+        tp += a; fp += b; fn += c
+    return prec_rec_f1(tp, fp, fn) + (tp, fp, fn)
+
+
+def evaluate_dataset(dets_source, gt_source, conf_thr, iou_thr, device=None):
+    """Detect_OBB.py:650-658 -> (P, R, F1)"""
+    tp = fp = fn = 0
+    for img, gts in gt_source.items():
+        filtered = [d for d in dets_source.get(img, []) if d[9] >= conf_thr]
+        a, b, c = match_dets_to_gts_pixel(filtered, gts, iou_thr, device)
+        tp += a; fp += b; fn += c
+    return prec_rec_f1(tp, fp, fn)
+
+
+def classwise_report(dets_source, gt_source, conf_thr, iou_thr, class_names=None, csv_path=None, device=None):
+    """Detect_OBB.py:660-686: rows [cls_id, class, TP, FP, FN, Precision, Recall, F1] for every class that has a detection
+    (CSV instead of the reference's xlsx when csv_path is given)."""
+    cids = sorted({int(d[8]) for dets in dets_source.values() for d in dets})
+    rows = []
+    for cid in cids:
+        tp = fp = fn = 0
+        for img, gts in gt_source.items():
+            dets_c = [d for d in dets_source.get(img, []) if int(d[8]) == cid and d[9] >= conf_thr]
+            a, b, c = match_dets_to_gts_pixel(dets_c, [g for g in gts if g["cls"] == cid], iou_thr, device)
+            tp += a; fp += b; fn += c
+        rows.append([cid, (class_names or {}).get(cid, str(cid)), tp, fp, fn, *prec_rec_f1(tp, fp, fn)])
+    if csv_path:
+        with open(csv_path, "w") as f:
+            f.write("cls_id,class,TP,FP,FN,Precision,Recall,F1\n")
+            for r in rows:
+                f.write(",".join(str(v) for v in r) + "\n")
+    return rows

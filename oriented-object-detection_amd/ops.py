@@ -71,6 +71,18 @@ def poly_iou_matrix(a, b, cls_a=None, cls_b=None):
     return out
 
 
+def points_in_quads(pts, quads, cls_p=None, cls_q=None):
+    """[np, nq] uint8: point i strictly inside the valid quad j (same class when both class vectors are given)"""
+    pts = _chk(pts, torch.float64, "pts").reshape(-1, 2)
+    quads = _chk(quads, torch.float64, "quads").reshape(-1, 8)
+    if cls_p is not None:
+        _chk(cls_p, torch.int32, "cls_p")
+        _chk(cls_q, torch.int32, "cls_q")
+    out = torch.zeros((pts.shape[0], quads.shape[0]), dtype=torch.uint8, device=pts.device)
+    _call("obb_points_in_quads", ctx(pts.device), _p(pts), _p(cls_p), pts.shape[0], _p(quads), _p(cls_q), quads.shape[0], _p(out), _stream())
+    return out
+
+
 # ---------------------------------------------------------------- S3 merge_detections
 
 def sort_desc_stable(key):

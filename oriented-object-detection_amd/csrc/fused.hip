@@ -177,7 +177,7 @@ __device__ __forceinline__ void fused_dw(const FusedStep &S, const FusedParams &
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = acc[j] + bb[j];
-            if (S.act) v = v / (1.0f + __expf(-v));
+            if (S.act) v = silu_f(v);
             acc[j] = zero ? 0.f : v;
         }
         *reinterpret_cast<uint4 *>(smem + S.out_off + ((ty + S.out_y0) * S.out_w + tx + S.out_x0) * S.out_pst + S.out_cb + c8 * 16) = pack8<F16>(acc);

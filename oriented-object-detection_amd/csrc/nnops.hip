@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = acc[p][j] + bb[j];
-            if (act) v = v / (1.0f + __expf(-v));
+            if (act) v = silu_f(v);
             acc[p][j] = v;
         }
         int64_t opix = (int64_t)y * W + x;

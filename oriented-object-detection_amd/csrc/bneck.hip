@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_bneck_stripe(const BneckParams P) {
         issue(min(s + 1, s1 - 1));  // unconditional (the last stripe re-reads its own rows): keeps the outstanding-op count exact
 
         // ---- conv 1: 3x3, C -> C/2, SiLU, rows oy0-1 .. oy0+R of the level -> T (zero outside the image)
-#pragma unroll
+        // (no global memory traffic in this loop: it need not be unrolled for the vmcnt bookkeeping, and rolling it keeps registers down)
+#pragma unroll 2
         for (int i = 0; i < FPW1; ++i) {
             int p = (wave + 4 * i) * 16 + pl;
             p = p < NPX1 ? p : NPX1 - 1;

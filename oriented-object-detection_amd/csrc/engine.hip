@@ -109,6 +109,8 @@ struct Model {
     float width = 0, depth = 0;
     std::string scale;
     std::map<std::string, ConvRecord> recs;
+    std::map<std::string, std::pair<std::vector<float>, std::vector<float>>> merged;  // weights / bias of synthesised (cout-concatenated) records
+    bool hmerge = true;  // sibling convs on the same input run as one launch (OBB_HMERGE=0 / "tail" = 0: separate, every tap observable)
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     bf16_t *lut_dev = nullptr;
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
@@ -330,6 +332,28 @@ struct Builder {
         P.ops.push_back(op);
     }
 
+    // Two sibling convs of the same kind on the same input (same k, stride, activation) as ONE conv whose weights are concatenated along
+    // cout: `out` = [outputs of a | outputs of b].  Returns the name of the synthesised record ("" if the pair does not qualify).
+    std::string merged_record(const std::string &na, const std::string &nb) {
+        if (!M.hmerge) return "";
+        const ConvRecord *a = rec(na), *b = rec(nb);
+        if (!a || !b || err) return "";
+        if (a->g != 1 || b->g != 1 || a->k != b->k || a->s != b->s || a->act != b->act || a->c1 != b->c1) return "";
+        const std::string nm = na + "|" + nb;
+        if (!M.recs.count(nm)) {
+            auto &st = M.merged[nm];
+            const size_t wa = (size_t)a->c2 * a->c1 * a->k * a->k, wb = (size_t)b->c2 * b->c1 * b->k * b->k;
+            st.first.assign(a->w, a->w + wa);
+            st.first.insert(st.first.end(), b->w, b->w + wb);
+            st.second.assign(a->b, a->b + a->c2);
+            st.second.insert(st.second.end(), b->b, b->b + b->c2);
+            ConvRecord r = *a;
+            r.name = nm; r.c2 = a->c2 + b->c2; r.w = st.first.data(); r.b = st.second.data();
+            M.recs[nm] = r;
+        }
+        return nm;
+    }
+
     void bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e) {
         int c_ = (int)(out.C * e);
         const bool bneck_on = !(getenv("OBB_BNECK") && atoi(getenv("OBB_BNECK")) == 0);
@@ -364,6 +388,24 @@ struct Builder {
 
     void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
         int c_ = out.C / 2;
+        const std::string mn = n >= 2 ? merged_record(name + ".cv1", name + ".cv2") : std::string();
+        if (!mn.empty()) {
+            // cv1 and cv2 read the same tensor: one launch writes [a | b]; the last Bottleneck later overwrites the (then dead) `a` member, so
+            // the same buffer is cv3's concat input.  Members are dense blocks (channel-blocked buffer).
+            int ab = buf(H, W, 2 * c_, name + ".cat", false, c_);
+            conv(mn, in, H, W, whole(ab));
+            P.named[name + ".cv1"] = sub(ab, 0, c_);
+            Slice cur = sub(ab, 0, c_);
+            for (int i = 0; i < n; ++i) {
+                Slice dst = (i == n - 1) ? sub(ab, 0, c_) : whole(buf(H, W, c_, name + ".m" + std::to_string(i)));
+                bottleneck(name + ".m." + std::to_string(i), cur, H, W, dst, 1.0);
+                cur = dst;
+            }
+            P.named[name + ".cv2"] = sub(ab, c_, c_);
+            conv(name + ".cv3", whole(ab), H, W, out);
+            return;
+        }
+        if (err) return;
         int cat = buf(H, W, 2 * c_, name + ".cat");
         int a = buf(H, W, c_, name + ".a");
         conv(name + ".cv1", in, H, W, whole(a));
@@ -679,10 +721,32 @@ struct Builder {
         for (int i = 0; i < 3; ++i) { P.lvl_off[i] = off; off += Hs[i] * Ws[i]; }
         P.A = off;
         auto mark_branch = [&](size_t first, int lane, int level) { (void)first; (void)lane; (void)level; };  // (branch lanes retired: see run_round)
+        Slice u1s[3];  // first conv of the angle branch, when it ran merged with the box branch's first conv
         for (int i = 0; i < 3; ++i) {
             size_t first_op = P.ops.size();
-            std::string p = "model.23.cv2." + std::to_string(i);
-            int t1 = buf(Hs[i], Ws[i], c2, p + ".t1"), t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
+            std::string p = "model.23.cv2." + std::to_string(i), p4 = "model.23.cv4." + std::to_string(i);
+            // (only where a layer is one tile per image and therefore latency-bound: at the larger levels the padded second cout block costs
+            //  more MFMA time than the saved launch and input read are worth -- measured)
+            const std::string mn = (c2 % 16 == 0 && c4 % 16 == 0 && Hs[i] * Ws[i] <= 256) ? merged_record(p + ".0", p4 + ".0") : std::string();
+            if (err) return err;
+            int t1, t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
+            if (!mn.empty()) {  // box and angle branch start with a 3x3 conv on the same feature map: one launch, [t1 | u1] in 16-channel blocks
+                int hb = buf(Hs[i], Ws[i], c2 + c4, p + ".t1u1", false, 16);
+                conv(mn, whole(feats[i]), Hs[i], Ws[i], whole(hb));
+                P.named[p + ".0"] = sub(hb, 0, c2);
+                P.named[p4 + ".0"] = sub(hb, c2, c4);
+                u1s[i] = sub(hb, c2, c4);
+                Slice t1s = sub(hb, 0, c2);
+                if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
+                    conv(p + ".1", t1s, Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i, nullptr, (p + ".2").c_str());
+                } else {
+                    conv(p + ".1", t1s, Hs[i], Ws[i], whole(t2));
+                    conv(p + ".2", whole(t2), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i);
+                }
+                mark_branch(first_op, 1, i);
+                continue;
+            }
+            t1 = buf(Hs[i], Ws[i], c2, p + ".t1");
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(t1));
             if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
                 conv(p + ".1", whole(t1), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i, nullptr, (p + ".2").c_str());
@@ -715,12 +779,17 @@ struct Builder {
             std::string p = "model.23.cv4." + std::to_string(i);
             if (M.fuse && fused_head_angle(p, whole(feats[i]), Hs[i], Ws[i], c4, i)) continue;
             if (err) return err;
-            int u1 = buf(Hs[i], Ws[i], c4, p + ".u1"), u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
-            conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
+            int u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
+            Slice u1sl = u1s[i];
+            if (u1sl.buf < 0) {
+                int u1 = buf(Hs[i], Ws[i], c4, p + ".u1");
+                conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(u1));
+                u1sl = whole(u1);
+            }
             if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
-                conv(p + ".1", whole(u1), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i, nullptr, (p + ".2").c_str());
+                conv(p + ".1", u1sl, Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i, nullptr, (p + ".2").c_str());
             } else {
-                conv(p + ".1", whole(u1), Hs[i], Ws[i], whole(u2));
+                conv(p + ".1", u1sl, Hs[i], Ws[i], whole(u2));
                 conv(p + ".2", whole(u2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax + M.nc, 1}, Slice(), i);
             }
             mark_branch(first_op, 3, i);
@@ -918,6 +987,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
     M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
     M->upfold = !(getenv("OBB_UPFOLD") && atoi(getenv("OBB_UPFOLD")) == 0);
+    M->hmerge = M->tail && !(getenv("OBB_HMERGE") && atoi(getenv("OBB_HMERGE")) == 0);
     M->bneck = M->tail;  // both swallow intermediate activations: one switch ("tail" = 0 keeps every layer observable)
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);

@@ -122,38 +122,59 @@ __global__ __launch_bounds__(256) void k_maxpool5(TensorRef in, TensorRef out, i
 
 // ---------------------------------------------------------------- SPPF: the three chained MaxPool2d(5,1,2) in one launch
 // out slices 1..3 of the concat buffer = pool(x), pool(pool(x)), pool(pool(pool(x))).  One workgroup owns (image, 32 channels): the
-// H x W plane lives in LDS and is pooled three times in place (ping-pong), each result stored as it appears.  `cat` is the concat
+// H x W plane lives in LDS and is pooled three times (separable 5x1 / 1x5 max), each result stored as it appears.  `cat` is the concat
 // buffer [x | y1 | y2 | y3] with C channels per member.
+// max of two 8-channel chunks in the storage type (max is exact in any format: no conversion to fp32 needed for fp16)
+template <bool F16>
+__device__ __forceinline__ uint4 max8(uint4 a, uint4 b) {
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+        h8 x, y;
+        __builtin_memcpy(&x, &a, 16);
+        __builtin_memcpy(&y, &b, 16);
+        h8 m = __builtin_elementwise_max(x, y);  // v_pk_max_f16
+        uint4 o;
+        __builtin_memcpy(&o, &m, 16);
+        return o;
+    } else {
+        float fa[8], fb[8];
+        unpack8<false>(a, fa);
+        unpack8<false>(b, fb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] = fmaxf(fa[j], fb[j]);
+        return pack8<false>(fa);
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void k_sppf_pools(TensorRef cat, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) uint4 sp[];  // two planes [H*W][4 chunks]
+    extern __shared__ __attribute__((aligned(16))) uint4 sp[];  // two planes [H*W][4 chunks]: current tensor, row-max scratch
     const int groups = C >> 5;
     const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
     const int n = H * W * 4;
     bf16_t *base = (bf16_t *)cat.p + (int64_t)b * cat.bs + cat.co + cg * 32;
-    uint4 *cur = sp, *nxt = sp + n;
+    uint4 *cur = sp, *tmp = sp + n;
     for (int i = threadIdx.x; i < n; i += 256) cur[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)(i >> 2) * cat.cs + (i & 3) * 8);
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
+        // 5x5 max = 1x5 max of the 5x1 max (window clipped at the border = implicit -inf padding)
         for (int i = threadIdx.x; i < n; i += 256) {
             const int pix = i >> 2, c = i & 3;
             const int y = pix / W, x = pix - y * W;
-            float m[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
-            for (int yy = max(0, y - 2); yy <= min(H - 1, y + 2); ++yy)
-                for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) {
-                    float f[8];
-                    unpack8<F16>(cur[(yy * W + xx) * 4 + c], f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
-                }
-            uint4 o = pack8<F16>(m);
-            nxt[i] = o;
-            *reinterpret_cast<uint4 *>(base + (int64_t)pass * C + (int64_t)pix * cat.cs + c * 8) = o;
+            uint4 m = cur[i];
+            for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) m = max8<F16>(m, cur[(y * W + xx) * 4 + c]);
+            tmp[i] = m;
         }
         __syncthreads();
-        uint4 *t = cur; cur = nxt; nxt = t;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int pix = i >> 2, c = i & 3;
+            const int y = pix / W, x = pix - y * W;
+            uint4 m = tmp[i];
+            for (int yy = max(0, y - 2); yy <= min(H - 1, y + 2); ++yy) m = max8<F16>(m, tmp[(yy * W + x) * 4 + c]);
+            cur[i] = m;  // (element i of `cur` is read only by this thread in this loop: in place)
+            *reinterpret_cast<uint4 *>(base + (int64_t)pass * C + (int64_t)pix * cat.cs + c * 8) = m;
+        }
+        __syncthreads();
     }
 }
 

@@ -14,6 +14,7 @@
 #include <tuple>
 
 #include "bneck.h"
+#include "c3kimg.h"
 #include "ctx.h"
 #include "fused.h"
 #include "nnops.h"
@@ -43,7 +44,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG };
 
 struct Op {
     OpType type;
@@ -55,6 +56,7 @@ struct Op {
     FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
+    C3kImgLaunch c3kimg;     // OP_C3KIMG (inner C3k of the stride-32 level, one persistent workgroup per image)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
     bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
@@ -388,6 +390,48 @@ struct Builder {
 
     void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
         int c_ = out.C / 2;
+        const bool img_on = M.hmerge && !(getenv("OBB_C3KIMG") && atoi(getenv("OBB_C3KIMG")) == 0);
+        if (img_on && in.buf >= 0 && out.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !P.bufs[out.buf].blk &&
+            c3kimg_supported(H, W, in.C, c_, out.C, n)) {
+            // the whole block in one launch: weight stream = the six layers' MFMA fragments back to back
+            const std::string names[6] = {name + ".cv1", name + ".cv2", name + ".m.0.cv1", name + ".m.0.cv2", name + ".m.1.cv1", name + ".m.1.cv2"};
+            const ConvRecord *r[7];
+            bool ok = true;
+            for (int i = 0; i < 6; ++i) { r[i] = rec(names[i]); ok = ok && r[i]; }
+            r[6] = rec(name + ".cv3"); ok = ok && r[6];
+            if (!ok || err) return;
+            auto is = [](const ConvRecord *q, int k, int c1, int c2) { return q->k == k && q->s == 1 && q->g == 1 && q->act && q->c1 == c1 && q->c2 == c2; };
+            if (is(r[0], 1, in.C, c_) && is(r[1], 1, in.C, c_) && is(r[2], 3, c_, c_) && is(r[3], 3, c_, c_) && is(r[4], 3, c_, c_) && is(r[5], 3, c_, c_) &&
+                is(r[6], 1, 2 * c_, out.C)) {
+                std::vector<bf16_t> stream;
+                std::vector<float> bias(6 * 128, 0.f);
+                auto add = [&](const float *w, int cout, int cin, int ks) {
+                    ConvTiling t{1, 1, 1, 4, cin};
+                    std::vector<bf16_t> pk = pack_conv_weights(w, cout, cin, ks, t, nullptr, 0, M.f16);
+                    stream.insert(stream.end(), pk.begin(), pk.end());
+                };
+                std::vector<float> w01((size_t)2 * c_ * in.C);
+                std::copy(r[0]->w, r[0]->w + (size_t)c_ * in.C, w01.begin());
+                std::copy(r[1]->w, r[1]->w + (size_t)c_ * in.C, w01.begin() + (size_t)c_ * in.C);
+                add(w01.data(), 2 * c_, in.C, 1);
+                for (int c = 0; c < c_; ++c) { bias[c] = r[0]->b[c]; bias[c_ + c] = r[1]->b[c]; }
+                for (int i = 2; i < 6; ++i) {
+                    add(r[i]->w, c_, c_, 3);
+                    for (int c = 0; c < c_; ++c) bias[(i - 1) * 128 + c] = r[i]->b[c];
+                }
+                add(r[6]->w, out.C, 2 * c_, 1);
+                for (int c = 0; c < out.C; ++c) bias[5 * 128 + c] = r[6]->b[c];
+                if ((int)(stream.size() / 8) != c3kimg_pieces()) { err = set_error(ctx, OBB_ERR_STATE, "c3k image kernel: weight stream has %zu pieces", stream.size() / 8); return; }
+                Op op;
+                op.type = OP_C3KIMG; op.name = name; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+                op.c3kimg.wts = upload(stream); op.c3kimg.bias = upload(bias); op.c3kimg.f16 = M.f16;
+                op.macs = (double)H * W * ((double)in.C * 2 * c_ + 4.0 * 9 * c_ * c_ + 2.0 * c_ * out.C);
+                P.macs_per_img += op.macs;
+                P.ops.push_back(op);
+                P.named[name + ".cv3"] = out;
+                return;
+            }
+        }
         const std::string mn = n >= 2 ? merged_record(name + ".cv1", name + ".cv2") : std::string();
         if (!mn.empty()) {
             // cv1 and cv2 read the same tensor: one launch writes [a | b]; the last Bottleneck later overwrites the (then dead) `a` member, so
@@ -896,6 +940,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 break;
             }
             case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
+            case OP_C3KIMG: {
+                C3kImgLaunch L = op.c3kimg;
+                L.B = B; L.in = tref(P, op.in, boff); L.out = tref(P, op.out, boff);
+                e = launch_c3kimg(L, st);
+                break;
+            }
             case OP_BNECK: {
                 BneckLaunch L = op.bneck;
                 L.B = B; L.y1 = tref(P, op.in, boff); L.y2 = tref(P, op.out, boff);
@@ -1114,6 +1164,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             }
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
+            case OP_C3KIMG: snprintf(line, sizeof line, "c3kimg %s c%d out%dx%d macs%.0f\n", op.name.c_str(), op.in.C, op.Ho, op.Wo, op.macs); break;
             case OP_BNECK: snprintf(line, sizeof line, "bneck %s c%d out%dx%d rows4 macs%.0f\n", op.name.c_str(), op.bneck.C, op.Ho, op.Wo, op.macs); break;
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;

@@ -104,7 +104,8 @@ def test_upsample_concat_read_in_place(ops, net_n, h, w, B, monkeypatch):
 def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B, monkeypatch):
     """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""
     x = torch.as_tensor(_tiles(55 + h + w, B, h, w)).cuda()
-    monkeypatch.setenv("OBB_BNECK", "0")  # (the fused Bottleneck shares the "tail" switch but sums its k in a different order)
+    monkeypatch.setenv("OBB_BNECK", "0")   # (the fused Bottleneck and the per-image C3k kernel share the "tail" switch but sum their k
+    monkeypatch.setenv("OBB_C3KIMG", "0")  #  in one channel stage where the separate kernels use several: 1-ulp flips, tested below)
     ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=False)
     ref = ops.forward(x).clone()
     ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=True)
@@ -114,6 +115,27 @@ def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B, monkeypatch)
     torch.cuda.synchronize()
     d = (got[..., :77] - ref[..., :77]).abs()
     assert float(d.max()) <= 1e-5, float(d.max())
+
+
+def test_c3k_image_kernel(ops, net_n, monkeypatch):
+    """Inner C3k of the stride-32 level as one persistent workgroup per image (c3kimg.hip) vs the same block as separate launches
+    (identical inputs: only this block's implementation differs).  Same rounding points; the 3x3 convs sum all 64 input channels in one
+    k loop instead of four channel stages -> rare 1-ulp flips that propagate through the block's six layers."""
+    B, h, w = 3, 416, 416
+    x = torch.as_tensor(_tiles(17, B, h, w)).cuda()
+    monkeypatch.setenv("OBB_C3KIMG", "0")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert not any(l.startswith("c3kimg ") for l in ops.debug_plan(h, w))
+    ops.forward(x)
+    ref = {n: ops.debug_activation(n, B, h, w).clone() for n in ("model.8.m.0.cv3", "model.8.cv2")}
+    monkeypatch.delenv("OBB_C3KIMG")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert sum(l.startswith("c3kimg ") for l in ops.debug_plan(h, w)) == 2
+    ops.forward(x)
+    for n, r in ref.items():
+        d = (ops.debug_activation(n, B, h, w) - r).abs()
+        print(n, float(d.max()), float(d.mean()), float(r.abs().mean()))
+        assert float(d.mean()) < (1e-3 if net_n.prec == "f16" else 1e-2) and float(d.max()) < (0.05 if net_n.prec == "f16" else 0.4)
 
 
 def test_fused_bottleneck_stripes(ops, net_n):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: 416-px tiles/sec of the Detect_OBB.py hot path on MI355X (BASELINE.json).
 
-A "step" is one pass of the hot path over one batch of synthetic 416x416x3 tiles that are already resident in HBM
+A "step" is one pass of the hot path over one batch (default 1024) of synthetic 416x416x3 tiles that are already resident in HBM
 (config[1]: YOLOv11n-OBB 3-ch 416x416 tiled inference, single scale):
     uint8 tiles -> fused preprocess + YOLO11n-OBB forward (MFMA implicit-GEMM convs) -> decode -> ProbIoU Fast-NMS
     -> result construction -> border filter -> per-tile polygon-IoU merge -> [N>1: RCCL all-gather of survivor records]
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 256)), help="tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 1024)), help="tiles per GPU per step (SURVEY 8(d): B in {1, 16, 64, 256, 1024})")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -194,6 +194,17 @@ def main():
         dt = float(tmax.item())
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev])) if fwd_ev else float("nan")
 
+    def profiled_traffic():
+        """HBM bytes of one forward from the committed rocprofv3 PMC passes of this build (FETCH_SIZE x2 + WRITE_SIZE, collected at 256
+        tiles, see tools/profile_all.sh), scaled to this step's tiles; None if the profile is not there."""
+        import re
+        try:
+            head = open(os.path.join(ROOT, "profiles", "r01_forward_hbm_traffic_b256.txt")).read(600)
+            m = re.search(r"-> ([0-9.]+) MB / tile", head)
+            return float(m.group(1)) * 1e6 * B if m else None
+        except OSError:
+            return None
+
     if rank == 0:
         tiles_per_s = world * B * args.steps / dt
         achieved = B * FLOP_PER_TILE / (fwd_ms * 1e-3) / 1e12
@@ -207,7 +218,8 @@ def main():
                        "tiles_per_gpu_per_step": B, "step_pipelining": bool(args.pipeline), "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
                        "survivor_records_per_step": nrec, "final_detections": nmerged},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": None, "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},
+                         "traffic": profiled_traffic(), "traffic_source": "profiles/r01_forward_hbm_traffic_b256.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                         "passes of this build, bytes per tile x tiles per step)", "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -111,6 +111,7 @@ struct Model {
     float width = 0, depth = 0;
     std::string scale;
     std::map<std::string, ConvRecord> recs;
+    int nrec_blob = 0;  // records of the weight blob itself (synthesised merged records are added to `recs` while plans are built)
     std::map<std::string, std::pair<std::vector<float>, std::vector<float>>> merged;  // weights / bias of synthesised (cout-concatenated) records
     bool hmerge = true;  // sibling convs on the same input run as one launch (OBB_HMERGE=0 / "tail" = 0: separate, every tap observable)
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
@@ -157,6 +158,7 @@ static int parse_blob(obb_ctx *ctx, Model &M) {
         c.b = reinterpret_cast<const float *>(M.blob.data() + R.b_off);
         M.recs[c.name] = c;
     }
+    M.nrec_blob = (int)M.recs.size();
     return OBB_OK;
 }
 
@@ -1082,7 +1084,7 @@ int obb_model_info(const obb_ctx *cctx, int32_t h, int32_t w, int32_t *nc, int32
     if (!ctx->model) return set_error(ctx, OBB_ERR_STATE, "no model loaded");
     if (nc) *nc = ctx->model->nc;
     if (ch) *ch = ctx->model->ch;
-    if (nconv) *nconv = (int32_t)ctx->model->recs.size();
+    if (nconv) *nconv = (int32_t)ctx->model->nrec_blob;
     if (anchors) {
         OBB_REQUIRE(ctx, h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0, "obb_model_info: h, w must be multiples of 32");
         *anchors = (h / 8) * (w / 8) + (h / 16) * (w / 16) + (h / 32) * (w / 32);

@@ -35,6 +35,8 @@ def test_model_info(ops, net_n):
     info = ops.model_info(416, 416)
     assert info == {"nc": 12, "ch": 3, "anchors": 3549, "nconv": 96}
     assert ops.model_info(128, 128)["anchors"] == 336
+    ops.forward(torch.as_tensor(_tiles(0, 1, 416, 416)).cuda())  # building a plan synthesises merged records: the blob's count must not change
+    assert ops.model_info(416, 416)["nconv"] == 96
 
 
 ALL_TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.3", "model.4.cv2",

@@ -173,35 +173,40 @@ __global__ __launch_bounds__(512) void k_c3k_image(const C3kImgParams P) {
         if constexpr (lc == 0 || L == 0 || L == 5) zero_acc();  // layer start / every cout block of the 1x1 layers
         // ---- the chunk's k-steps
         const char *wl = smem + OFF_W + (ci & 1) * WBUF_B;
+        // software-pipelined: the operands of k-step ks+1 are requested from LDS before the MFMAs of k-step ks are issued
+        hx8 wc[2][2], ac[2][3];
+        auto fetch_ops = [&](auto ks_const) {
+            constexpr int ks = decltype(ks_const)::value;
+            constexpr int sl = ks & 1;
 #pragma unroll
-        for (int ks = 0; ks < ksteps_of(ci); ++ks) {
-            hx8 wcur[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) wcur[f] = *reinterpret_cast<const hx8 *>(wl + ((ks * 4 + half * 2 + f) * 64 + lane) * 16);
-            hx8 a[3];
+            for (int f = 0; f < 2; ++f) wc[sl][f] = *reinterpret_cast<const hx8 *>(wl + ((ks * 4 + half * 2 + f) * 64 + lane) * 16);
             if constexpr (L == 0) {  // 1x1 over the 128-channel input image: k-step kk of 4 -> chunk q = kk*4 + g
-                const int kk = ks;
 #pragma unroll
-                for (int mf = 0; mf < 3; ++mf) a[mf] = *reinterpret_cast<const hx8 *>(smem + OFF_IN + o_in[mf] + (kk * 4 + g) * 16);
-            } else if constexpr (L == 5) {  // 1x1 over [a' | b]
-                const int kk = ks;
-                const int q = kk * 4 + g;  // 0..15: chunks 0..7 = a' (bordered image A), 8..15 = b
+                for (int mf = 0; mf < 3; ++mf) ac[sl][mf] = *reinterpret_cast<const hx8 *>(smem + OFF_IN + o_in[mf] + (ks * 4 + g) * 16);
+            } else if constexpr (L == 5) {  // 1x1 over [a' | b]: chunks 0..7 = a' (bordered image A), 8..15 = b
+                const int q = ks * 4 + g;
 #pragma unroll
                 for (int mf = 0; mf < 3; ++mf)
-                    a[mf] = kk < 2 ? *reinterpret_cast<const hx8 *>(smem + OFF_A + o_int[mf] + q * 16)
-                                   : *reinterpret_cast<const hx8 *>(smem + OFF_BB + o_bb[mf] + (q - 8) * 16);
+                    ac[sl][mf] = ks < 2 ? *reinterpret_cast<const hx8 *>(smem + OFF_A + o_int[mf] + q * 16)
+                                        : *reinterpret_cast<const hx8 *>(smem + OFF_BB + o_bb[mf] + (q - 8) * 16);
             } else {  // 3x3 over a bordered 64-channel image: k-step kk of 18 -> chunk q = kk*4 + g -> (tap, 8-channel chunk)
                 const int kk = lc * 6 + ks;
                 const int q = kk * 4 + g, tap = q >> 3, c8 = q & 7, dy = tap / 3, dx = tap - dy * 3;
                 const int src = (L == 1 || L == 3) ? OFF_A : OFF_T;
 #pragma unroll
-                for (int mf = 0; mf < 3; ++mf) a[mf] = *reinterpret_cast<const hx8 *>(smem + src + o_bord[mf] + (dy * BW + dx) * P64 + c8 * 16);
+                for (int mf = 0; mf < 3; ++mf) ac[sl][mf] = *reinterpret_cast<const hx8 *>(smem + src + o_bord[mf] + (dy * BW + dx) * P64 + c8 * 16);
             }
+        };
+        auto kstep = [&](auto ks_const) {
+            constexpr int ks = decltype(ks_const)::value;
+            if constexpr (ks + 1 < ksteps_of(ci)) fetch_ops(std::integral_constant<int, ks + 1>{});
 #pragma unroll
             for (int mf = 0; mf < 3; ++mf)
 #pragma unroll
-                for (int f = 0; f < 2; ++f) acc[mf][f] = HX<F16>::mfma(wcur[f], a[mf], acc[mf][f]);
-        }
+                for (int f = 0; f < 2; ++f) acc[mf][f] = HX<F16>::mfma(wc[ks & 1][f], ac[ks & 1][mf], acc[mf][f]);
+        };
+        fetch_ops(std::integral_constant<int, 0>{});
+        for_each_chunk(kstep, std::make_integer_sequence<int, ksteps_of(ci)>{});
         // ---- layer / cout-block boundaries
         if constexpr (L == 0 && lc == 0) epilogue(0, 0, o_int, OFF_A, -1);       // a  = SiLU(cv1 x)
         if constexpr (L == 0 && lc == 1) epilogue(0, 1, o_bb, OFF_BB, -1);       // b  = SiLU(cv2 x)

@@ -119,6 +119,19 @@ def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B, monkeypatch)
     assert float(d.max()) <= 1e-5, float(d.max())
 
 
+def test_concurrent_chains_and_rounds_match_small_batches(ops, net_n):
+    """A large batch is walked in rounds, each issued as two concurrent half-batch chains that address their own image range of every
+    activation buffer (plain, channel-blocked and virtual-concat ones alike): the result must equal the same tiles run in small calls."""
+    B = 600  # rounds of 512 + 88 tiles, both split into two chains
+    x = torch.as_tensor(_tiles(5, B, 128, 128)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    big = ops.forward(x).clone()
+    big2 = ops.forward(x).clone()          # second call: hipGraph replay of the captured round
+    small = torch.cat([ops.forward(x[i:i + 50].contiguous()).clone() for i in range(0, B, 50)])
+    torch.cuda.synchronize()
+    assert torch.equal(big, small) and torch.equal(big2, small)
+
+
 def test_c3k_image_kernel(ops, net_n, monkeypatch):
     """Inner C3k of the stride-32 level as one persistent workgroup per image (c3kimg.hip) vs the same block as separate launches
     (identical inputs: only this block's implementation differs).  Same rounding points; the 3x3 convs sum all 64 input channels in one

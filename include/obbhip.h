@@ -65,6 +65,11 @@ int obb_poly_iou_matrix(obb_ctx *ctx, const double *a, const int32_t *cls_a, int
 int obb_points_in_quads(obb_ctx *ctx, const double *pts, const int32_t *cls_p, int64_t np, const double *quads, const int32_t *cls_q,
                         int64_t nq, uint8_t *out, obb_stream_t s);
 
+/* 4-channel network input (RGB + distance-transform edge channel) for every crop of a batch: `build_multich(crop_bgr, out_channels=4)`,
+ * Detect_OBB.py:87-133 (called per tile at :77).  bgr: uint8[B,h,w,3], out4: uint8[B,h,w,4] = [R, G, B, dt_edge].  The OpenCV steps
+ * are restated from their documented algorithms (cv2 is absent offline: parity with cv2 itself is unpinned). */
+int obb_build_multich(obb_ctx *ctx, const uint8_t *bgr, int32_t B, int32_t h, int32_t w, uint8_t *out4, obb_stream_t s);
+
 /* ------------------------------------------------------------------ S3: merge_detections  (Detect_OBB.py:176-200) */
 /* order[n] = stable descending argsort of key (Python list.sort(key=conf, reverse=True), Detect_OBB.py:183). */
 int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *order, obb_stream_t s);

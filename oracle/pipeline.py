@@ -18,6 +18,9 @@ class OracleModel:
         self.net, self.imgsz, self.precision, self.head_fn, self.iou, self.max_det = net, imgsz, precision, head_fn, iou, max_det
 
     def predict_rows(self, crop, conf):
+        if self.net.ch == 4 and crop.shape[2] == 3:  # run_inference_on_crop :76-77: net_input = build_multich(crop_bgr, channels)
+            from . import dtedge
+            crop = dtedge.build_multich(crop, 4)
         lb, p = pp.letterbox(crop, self.imgsz)
         h, w = lb.shape[:2]
         head = self.head_fn(lb[None]) if self.head_fn is not None else self.net.forward_raw(lb[None], self.precision)

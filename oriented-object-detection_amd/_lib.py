@@ -21,6 +21,7 @@ SIGNATURES = {
     "obb_poly_iou_pairs": [_V, _V, _V, C.c_int64, _V, _V],
     "obb_poly_iou_matrix": [_V, _V, _V, C.c_int64, _V, _V, C.c_int64, _V, _V],
     "obb_points_in_quads": [_V, _V, _V, C.c_int64, _V, _V, C.c_int64, _V, _V],
+    "obb_build_multich": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V],
     "obb_sort_desc_stable": [_V, _V, C.c_int64, _V, _V],
     "obb_nms_mask": [_V, _V, _V, C.c_int64, C.c_double, _V, _V],
     "obb_nms_reduce": [_V, _V, C.c_int64, _V, _V, _V],

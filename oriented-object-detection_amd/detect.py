@@ -116,6 +116,17 @@ def compute_polygon_iou(box1, box2):
 
 
 # ---------------------------------------------------------------- S3
+def build_multich(bgr, out_channels=4):
+    """Detect_OBB.py:87-133: HxWx3 BGR uint8 (numpy array or device tensor) -> HxWx3 unchanged, or HxWx4 = RGB + distance-transform
+    edge channel (computed on the device, returned in the container type that came in)."""
+    assert out_channels in (3, 4), f"Unsupported out_channels={out_channels}"
+    if out_channels == 3:
+        return np.ascontiguousarray(bgr) if isinstance(bgr, np.ndarray) else bgr.contiguous()
+    t = torch.as_tensor(np.ascontiguousarray(bgr)).cuda() if isinstance(bgr, np.ndarray) else bgr
+    out = ops.build_multich(t.contiguous()[None])[0]
+    return out.cpu().numpy() if isinstance(bgr, np.ndarray) else out
+
+
 def merge_detections_device(ds, iou_threshold=0.5):
     """-> (kept DetSet in confidence order, order tensor: sorted position -> input row)"""
     if len(ds) == 0:
@@ -259,10 +270,17 @@ def detect_symbols_records(image, model, tile_size, overlap, cfg=DEFAULT, conf=N
         for i0 in range(0, len(idxs), batch):
             part = idxs[i0:i0 + batch]
             pidx = torch.as_tensor(part, dtype=torch.int32, device=dev)
+            multich = C == 3 and getattr(model, "ch", C) == 4  # 4-channel checkpoints: RGB + DT-edge channel built per crop (:76-77, :87-133)
             if ch == cw == model.imgsz:
                 tiles, lb = ops.gather_tiles(image, rects_dev[pidx.long()].contiguous(), model.imgsz), None
+                if multich:
+                    tiles = ops.build_multich(tiles)
             else:
-                tiles = torch.stack([ops.letterbox(image, *[int(v) for v in rects[t]], model.imgsz)[0] for t in part])
+                if multich:  # the channel is computed on the raw crop, the letterbox comes after it (as in the reference)
+                    crops = ops.build_multich(torch.stack([image[rects[t][1]:rects[t][3], rects[t][0]:rects[t][2]] for t in part]).contiguous())
+                    tiles = torch.stack([ops.letterbox(crops[k].contiguous(), 0, 0, cw, ch, model.imgsz)[0] for k in range(len(part))])
+                else:
+                    tiles = torch.stack([ops.letterbox(image, *[int(v) for v in rects[t]], model.imgsz)[0] for t in part])
                 lb = torch.tensor([[p["gain"], p["pad_x"], p["pad_y"]]], dtype=torch.float32, device=dev).repeat(len(part), 1)
             parts.append(predict_tile_records(model, tiles, rects_dev, pidx, lb, cfg, tile_size, conf))
     if not parts:

@@ -125,6 +125,9 @@ class YOLO:
                         raise ValueError("predict: expected an HxWxC uint8 array (as Detect_OBB.py passes crops)")
                     im = torch.as_tensor(np.ascontiguousarray(im)).to(self.device)
                 H, W, C = im.shape
+                if C == 3 and self.ch == 4:  # run_inference_on_crop (Detect_OBB.py:76-77): net_input = build_multich(crop_bgr, 4)
+                    im = ops.build_multich(im.contiguous()[None])[0]
+                    C = 4
                 if C != self.ch:
                     raise ValueError(f"predict: model expects {self.ch} channels, got {C}")
                 lbimg, p = ops.letterbox(im.contiguous(), 0, 0, W, H, self.imgsz)

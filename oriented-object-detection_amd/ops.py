@@ -71,6 +71,15 @@ def poly_iou_matrix(a, b, cls_a=None, cls_b=None):
     return out
 
 
+def build_multich(bgr_tiles):
+    """uint8 [B,h,w,3] BGR crops -> uint8 [B,h,w,4] = RGB + distance-transform edge channel (Detect_OBB.py:87-133)"""
+    t = _chk(bgr_tiles, torch.uint8, "bgr_tiles")
+    assert t.dim() == 4 and t.shape[3] == 3
+    out = torch.empty((t.shape[0], t.shape[1], t.shape[2], 4), dtype=torch.uint8, device=t.device)
+    _call("obb_build_multich", ctx(t.device), _p(t), t.shape[0], t.shape[1], t.shape[2], _p(out), _stream())
+    return out
+
+
 def points_in_quads(pts, quads, cls_p=None, cls_q=None):
     """[np, nq] uint8: point i strictly inside the valid quad j (same class when both class vectors are given)"""
     pts = _chk(pts, torch.float64, "pts").reshape(-1, 2)

@@ -107,6 +107,35 @@ def test_detect_symbols_vs_oracle_pipeline(ood, nets, H, W, ts, ov, key):
     _compare_dets(got, exp)
 
 
+def test_four_channel_checkpoint_end_to_end(ood):
+    """BASELINE configs[3] (4-channel input): a 3-channel BGR image goes in, every crop gets its DT-edge channel on the device
+    (build_multich, Detect_OBB.py:76-77 / :87-133) before the letterbox; == the CPU restatement fed with the same network outputs."""
+    net = Yolo11OBB("n", nc=12, ch=4, seed=2)
+    model = ood.model.YOLO(net, imgsz=416)
+    assert model.ch == 4
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (600, 740, 3), dtype=np.uint8)
+    img[100:130, 50:600] = 15
+    img[200:520, 300:330] = (240, 10, 10)
+
+    def head_fn(t):
+        model._ensure_active()
+        return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()[..., :77]
+    om = opl.OracleModel(net, 416, head_fn=head_fn)
+    exp = opl.detect_symbols(img, om, 416, 100)
+    got = ood.detect.detect_symbols(img, model, 416, 100)      # 4 tiles: one full, three partial (letterboxed after the channel is built)
+    assert len(exp) > 5
+    _compare_dets(got, exp)
+    crop = np.ascontiguousarray(img[0:175, 0:263])
+    res = model(crop, conf=0.25)                               # the per-crop call surface builds the channel too
+    pts, cls, cf = om.predict_rows(crop, 0.25)
+    assert len(res[0].obb) == len(cls)
+    four = ood.detect.build_multich(crop, 4)
+    from oracle import dtedge
+    assert four.shape == (175, 263, 4) and np.abs(four.astype(np.int32) - dtedge.build_multich(crop, 4).astype(np.int32)).max() <= 1
+    assert np.array_equal(ood.detect.build_multich(crop, 3), crop)
+
+
 def test_process_image_dual_scale_vs_oracle(ood, nets):
     img = np.random.default_rng(9).integers(0, 256, (500, 640, 3), dtype=np.uint8)
 

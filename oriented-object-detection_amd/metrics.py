@@ -212,3 +212,29 @@ def classwise_report(dets_source, gt_source, conf_thr, iou_thr, class_names=None
             for r in rows:
                 f.write(",".join(str(v) for v in r) + "\n")
     return rows
+
+
+def run_fusion_eval(dets_source, gt_source, iou_thr=0.25, class_names=None, csv_path=None, verbose=True, device=None):
+    """Detect_OBB.py:688-741 (the single-scale and the dual-scale branch report the same quantities): the reference uses `iou_thr`
+    (:36, 0.25) BOTH as the confidence threshold of the P/R/F1, class-wise and Center-Hit reports and as their IoU threshold.
+    dets_source: {image: [11-tuples]} (what process_image stores in all_dets_per_image, :344-345); gt_source: {image: [{"cls", "pts"}]}.
+    -> dict with every number the reference prints."""
+    thr = float(iou_thr)
+    out = {"conf_thr": thr, "iou_thr": float(iou_thr)}
+    P, R, F1 = evaluate_dataset(dets_source, gt_source, conf_thr=thr, iou_thr=iou_thr, device=device)
+    out["precision"], out["recall"], out["f1"] = P, R, F1
+    out["classwise"] = classwise_report(dets_source, gt_source, conf_thr=thr, iou_thr=iou_thr, class_names=class_names, csv_path=csv_path, device=device)
+    ch = evaluate_center_hit(dets_source, gt_source, conf_thr=thr, device=device)
+    out["center_hit"] = {"P": ch[0], "R": ch[1], "F1": ch[2], "TP": ch[3], "FP": ch[4], "FN": ch[5]}
+    maps = evaluate_map(dets_source, gt_source, iou_list=list(np.arange(0.5, 0.96, 0.05)))
+    out["mAP@0.5"], out["mAP@[0.5:0.95]"] = maps["mAP@0.5"], maps["mAP@[0.5:0.95]"]
+    soft_list = [0.30, 0.40, 0.50, 0.60, 0.70]
+    maps_soft = evaluate_map(dets_source, gt_source, iou_list=soft_list)
+    out["mAP@0.3"] = maps_soft["per_iou"][0.30]
+    out["mAP@[0.3:0.7]"] = float(np.mean([maps_soft["per_iou"][i] for i in soft_list]))
+    if verbose:
+        print(f"[Report @ {thr:.2f}] Precision={P:.3f} | Recall={R:.3f} | F1={F1:.3f}")
+        print(f"[Center-Hit @ conf≥{thr:.2f}] P={ch[0]:.3f} R={ch[1]:.3f} F1={ch[2]:.3f} (TP={ch[3]}, FP={ch[4]}, FN={ch[5]})")
+        print(f"mAP@0.5 = {out['mAP@0.5']:.4f}\nmAP@[0.5:0.95] = {out['mAP@[0.5:0.95]']:.4f}")
+        print(f"mAP@0.3 = {out['mAP@0.3']:.4f}\nmAP@[0.3:0.7] = {out['mAP@[0.3:0.7]']:.4f}")
+    return out

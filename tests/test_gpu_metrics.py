@@ -92,3 +92,21 @@ def test_f2_metrics_match_reference_goldens(tmp_path):
     for c in cases["center_hit"]:  # expectations from the oracle's restatement (GEOS absent): device decisions are bit-identical to it
         assert metrics.evaluate_center_hit(dets, gts, c["conf_thr"]) == (c["P"], c["R"], c["F1"], c["tp"], c["fp"], c["fn"])
     assert metrics.match_dets_to_gts_pixel([], gts[0], 0.5) == (0, 0, len(gts[0])) and metrics.center_hit_counts(dets[0], []) == (0, len(dets[0]), 0)
+
+
+def test_run_fusion_eval_report(capsys):
+    """Detect_OBB.py:688-741: one threshold drives the P/R/F1, class-wise and Center-Hit reports (as confidence AND IoU threshold)."""
+    cases, dets, gts = _f2()
+    _, metrics = _gts()
+    rep = metrics.run_fusion_eval(dets, gts, iou_thr=0.5)
+    ds = next(c for c in cases["dataset"] if (c["conf_thr"], c["iou_thr"]) == (0.5, 0.5))
+    assert (rep["precision"], rep["recall"], rep["f1"]) == (ds["P"], ds["R"], ds["F1"])
+    cw = {c["cls"]: c for c in cases["classwise"] if (c["conf_thr"], c["iou_thr"]) == (0.5, 0.5)}
+    assert len(rep["classwise"]) == len(cw) and all((r[2], r[3], r[4]) == (cw[r[0]]["tp"], cw[r[0]]["fp"], cw[r[0]]["fn"]) for r in rep["classwise"])
+    ch = next(c for c in cases["center_hit"] if c["conf_thr"] == 0.5)
+    assert (rep["center_hit"]["TP"], rep["center_hit"]["FP"], rep["center_hit"]["FN"]) == (ch["tp"], ch["fp"], ch["fn"])
+    m = metrics.evaluate_map(dets, gts, iou_list=list(np.arange(0.5, 0.96, 0.05)))
+    assert rep["mAP@0.5"] == m["mAP@0.5"] and rep["mAP@[0.5:0.95]"] == m["mAP@[0.5:0.95]"] and 0.0 < rep["mAP@[0.5:0.95]"] < rep["mAP@0.5"] <= 1.0
+    assert rep["mAP@0.3"] >= rep["mAP@0.5"] and rep["mAP@0.3"] >= rep["mAP@[0.3:0.7]"] > 0
+    out = capsys.readouterr().out
+    assert "[Report @ 0.50]" in out and "mAP@[0.3:0.7]" in out and "[Center-Hit @ conf≥0.50]" in out

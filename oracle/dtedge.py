@@ -40,7 +40,10 @@ def gauss_kernel_q8(sigma):
 
 
 def _reflect101(idx, n):
-    idx = np.abs(idx)
+    """cv2 borderInterpolate(BORDER_REFLECT_101): folds until the index is inside, i.e. an even extension of period 2 (n - 1)"""
+    if n == 1:
+        return np.zeros_like(idx)
+    idx = np.mod(idx, 2 * (n - 1))
     return np.where(idx >= n, 2 * (n - 1) - idx, idx)
 
 

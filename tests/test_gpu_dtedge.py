@@ -26,10 +26,17 @@ def _images():
     grad[200:216, :] = 0
     out.append(grad)                                                     # full 416 x 416 tile
     out.append(np.full((64, 96, 3), 127, np.uint8))                      # constant: no edges at all
+    out.append(rng.integers(0, 256, (5, 9, 3), dtype=np.uint8))          # ragged border crop smaller than the blur radius: repeated reflection
+    yy, xx = np.mgrid[0:128, 0:128]
+    wave = (127 + 90 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.uint8)
+    out.append(np.stack([wave, wave.T, 255 - wave], -1))                 # the 128-px scale of the dual-scale run (2 pixels per lane)
+    wide = rng.integers(0, 256, (40, 600, 3), dtype=np.uint8)
+    wide[:, 300:] = (wide[:, 300:] // 32) * 32                            # many ties in the order statistics; 16 pixels per lane
+    out.append(wide)
     return out
 
 
-@pytest.mark.parametrize("idx", range(4))
+@pytest.mark.parametrize("idx", range(7))
 def test_build_multich_matches_numpy_restatement(idx):
     import oriented_object_detection_amd  # noqa: F401
     from oriented_object_detection_amd import ops

@@ -15,6 +15,19 @@ def test_grey_and_kernels():
     assert float(od.scharr_mag(flat).max()) == 0.0
 
 
+def test_reflect101_folds_repeatedly():
+    # cv2 borderInterpolate(BORDER_REFLECT_101): gfedcb|abcdefgh|gfedcba, repeated for offsets beyond one image length
+    assert od._reflect101(np.arange(-7, 10), 3).tolist() == [1, 2, 1, 0, 1, 2, 1, 0, 1, 2, 1, 0, 1, 2, 1, 0, 1]
+    assert od._reflect101(np.arange(-2, 7), 5).tolist() == [2, 1, 0, 1, 2, 3, 4, 3, 2]
+    assert od._reflect101(np.arange(-3, 4), 1).tolist() == [0] * 7
+    tiny = np.arange(15, dtype=np.uint8).reshape(3, 5) * 10
+    ref = np.pad(tiny.astype(np.int64), 7, mode="reflect")                # numpy folds repeatedly as well
+    q = od.gauss_kernel_q8(2.4)
+    row = sum(int(q[i]) * ref[7:10, i:i + 5] for i in range(15))
+    assert np.array_equal(od.gaussian_blur_u8(tiny, 2.4)[1], ((sum(int(q[i]) * sum(int(q[j]) * ref[1 + i, j:j + 5] for j in range(15)) for i in range(15)) + (1 << 15)) >> 16).astype(np.uint8))
+    assert row.shape == (3, 5)
+
+
 def test_scharr_open_distance():
     step = np.zeros((9, 9), np.uint8)
     step[:, 5:] = 10

@@ -47,6 +47,7 @@ struct ConvLaunch {
     const bf16_t *tail_wpk = nullptr;  // pack_conv_weights(w2, tail_cout, cout, 1, {.., NF = tail_cout <= 16 ? 1 : 4, CK = cout})
     const float *tail_bias = nullptr;  // padded to a multiple of 64 floats
     int tail_cout = 0;
+    bool tail_act16 = false;           // the tail has SiLU and writes ITS 16-bit result to `out` (cv1 of a C3k2 block behind a stride-2 conv)
     TensorRef tail_out;
     int tail_out_hw = 0;
     int out_hw = 0;  // > 0: 1-D launch whose OUTPUT is split per image: pixel P -> (b = P / out_hw, P % out_hw) with out.bs
@@ -68,7 +69,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w_oihw, int cout, int cin, in
 
 int conv_ksteps(int ks, int CK);
 size_t conv_lds_bytes(const ConvLaunch &L);
-bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2);
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16 = false);
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st);
 
 }  // namespace obb

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace obb {
 
@@ -55,7 +56,9 @@ struct ConvParams {
 // TAIL > 0: the layer is followed by a plain 1x1 conv (no activation) whose output goes to the head tensor: that second GEMM runs
 // on the staged 16-bit output tile while it is still in LDS (TAIL = its NF), and the intermediate tensor is never written.
 // VCAT: 1x1 over a virtual [upsample | skip] concat (ConvParams::up_c); a separate instantiation so that the plain kernels stay branch-free
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false>
+// T16: the trailing 1x1 has an activation and a 16-bit (possibly channel-blocked) output of its own -- the cv1 of the C3k2 block behind a
+// stride-2 backbone conv: its result replaces the staged tile in LDS and leaves through the same coalesced write-out.
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -312,6 +315,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         // ---- epilogue: lane owns couts [cbase, cbase + 4*NF) of its pixels: + bias, SiLU, + residual
         const bool full = (cbase + 4 * NF <= P.cout);
         constexpr int ROWB = 32 * NF + 16;  // staged output row: 16*NF halves + 16 B pad
+        // coalesced write-out of the staged 16-bit tile: consecutive lanes store consecutive 16-B pieces of a pixel's output row
+        // (CPP = 16-B chunks per pixel, occ0 = first 8-channel chunk of this group inside the output slice)
+        auto write_out = [&](auto cpp_c, int cout_o, int occ0) {
+            constexpr int CPP = decltype(cpp_c)::value;
+            const int npx = P.TH * P.TW;
+            bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co;
+            for (int i = tid; i < npx * CPP && !(P.dbg & 8); i += 256) {
+                int p = i / CPP, ch = i - p * CPP;
+                int ty = (int)(((float)p + 0.5f) * P.inv_tw);
+                int tx = p - ty * P.TW;
+                if (oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
+                const int occ = occ0 + ch;                 // 8-channel chunk index inside the output slice
+                if (occ * 8 + 8 > cout_o) continue;        // cout tail of the last block (cout is a multiple of 8)
+                uint4 o = *reinterpret_cast<const uint4 *>(smem + p * ROWB + ch * 16);
+                *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((int64_t)(oy0 + ty) * P.Wout + ox0 + tx) * P.out_cs +
+                                           ((occ & P.out_bmask) << 3)) = o;
+            }
+        };
         float bias[NF * 4];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -409,6 +430,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
                 }
             }
             const int c2base = g * 4 * TAIL;
+            if constexpr (T16) {
+                static_assert(TAIL <= NF, "the tail's 16-bit rows reuse the staging rows of the main layer");
+                // + bias, SiLU, 16 bit, back into this wave's OWN staging rows (its reads of them are complete: LDS ops are in order)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    float v[TAIL * 4];
+#pragma unroll
+                    for (int f = 0; f < TAIL; ++f) {
+                        float4 bv = *reinterpret_cast<const float4 *>(s_bias2 + c2base + f * 4);
+                        v[f * 4 + 0] = silu_f(acc2[mf][f][0] + bv.x); v[f * 4 + 1] = silu_f(acc2[mf][f][1] + bv.y);
+                        v[f * 4 + 2] = silu_f(acc2[mf][f][2] + bv.z); v[f * 4 + 3] = silu_f(acc2[mf][f][3] + bv.w);
+                    }
+                    char *orow = smem + ((wave * MF + mf) * 16 + pl) * ROWB + g * 8 * TAIL;
+                    if constexpr (TAIL == 1) {
+                        uint2 o;
+                        o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]);
+                        *reinterpret_cast<uint2 *>(orow) = o;
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < TAIL / 2; ++h) {
+                            uint4 o;
+                            o.x = HX<F16>::pack2(v[h * 8 + 0], v[h * 8 + 1]); o.y = HX<F16>::pack2(v[h * 8 + 2], v[h * 8 + 3]);
+                            o.z = HX<F16>::pack2(v[h * 8 + 4], v[h * 8 + 5]); o.w = HX<F16>::pack2(v[h * 8 + 6], v[h * 8 + 7]);
+                            *reinterpret_cast<uint4 *>(orow + h * 16) = o;
+                        }
+                    }
+                }
+                __syncthreads();
+                write_out(std::integral_constant<int, 2 * TAIL>(), P.cout2, 0);
+            } else {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
@@ -430,23 +481,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
                     }
                 }
             }
+            }
         } else if constexpr (!OUT_F32) {
             __syncthreads();
-            // coalesced write-out: consecutive lanes store consecutive 16-B pieces of a pixel's 32*NF-byte output row
-            constexpr int CPP = 2 * NF;  // 16-B chunks per pixel
-            const int npx = P.TH * P.TW;
-            bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co;
-            for (int i = tid; i < npx * CPP && !(P.dbg & 8); i += 256) {
-                int p = i / CPP, ch = i - p * CPP;
-                int ty = (int)(((float)p + 0.5f) * P.inv_tw);
-                int tx = p - ty * P.TW;
-                if (oy0 + ty >= P.Hout || ox0 + tx >= P.Wout) continue;
-                const int occ = cb * 2 * NF + ch;           // 8-channel chunk index inside the output slice
-                if (occ * 8 + 8 > P.cout) continue;        // cout tail of the last block (cout is a multiple of 8)
-                uint4 o = *reinterpret_cast<const uint4 *>(smem + p * ROWB + ch * 16);
-                *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((int64_t)(oy0 + ty) * P.Wout + ox0 + tx) * P.out_cs +
-                                           ((occ & P.out_bmask) << 3)) = o;
-            }
+            write_out(std::integral_constant<int, 2 * NF>(), P.cout, cb * 2 * NF);
         }
     }
 }
@@ -528,21 +566,31 @@ static size_t conv_main_lds(const ConvLaunch &L) {
     return (std::max(conv_act_bytes(L) + (size_t)conv_ksteps(L.ks, L.CK) * L.NF * 1024, out_tile) + 15) / 16 * 16;
 }
 
-static int tail_nf(int cout2) { return cout2 <= 16 ? 1 : 4; }
+static int tail_nf(int cout2) { return cout2 <= 16 ? 1 : (cout2 <= 32 ? 2 : 4); }
 
 size_t conv_lds_bytes(const ConvLaunch &L) {
     size_t t = L.tail_cout > 0 ? (size_t)conv_ksteps(1, 16 * L.NF) * tail_nf(L.tail_cout) * 1024 : 0;  // tail weights behind everything else
     return conv_main_lds(L) + t;
 }
 
-bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2) {
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16) {
     if (cout1 != 16 * NF || cout2 < 1 || cout2 > 64) return false;
     const int nf2 = tail_nf(cout2);
+    if (act16) return ks == 3 && MF == 3 && (NF == 2 || NF == 4) && nf2 == NF && cout2 == 16 * nf2;  // whole 16-bit rows of the staging area
     return (ks == 3 && MF == 3 && NF == 4 && nf2 == 4) || (ks == 3 && MF == 3 && NF == 1 && nf2 == 1) || (ks == 1 && MF == 2 && NF == 4 && nf2 == 1);
 }
 
 template <int KS, int MF, int NF, bool F16>
 static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.tail_cout > 0 && L.tail_act16) {  // stride-2 backbone conv + the cv1 of the following C3k2 block
+        if constexpr (KS == 3 && MF == 3 && (NF == 2 || NF == 4)) {
+            if (L.in_u8 || L.out_f32 || tail_nf(L.tail_cout) != NF) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16, NF, false, true>), grid, dim3(256), lds, st, P);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (L.tail_cout > 0) {  // only the three shapes of the OBB head are instantiated (conv_tail_supported)
         constexpr int T = (KS == 3 && MF == 3 && NF == 4) ? 4 : 1;
         if constexpr ((KS == 3 && MF == 3 && (NF == 4 || NF == 1)) || (KS == 1 && MF == 2 && NF == 4)) {
@@ -646,7 +694,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.w2pk = L.tail_wpk; P.bias2 = L.tail_bias; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs;
     P.out2_co = L.tail_out.co; P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.kst2 = conv_ksteps(1, 16 * L.NF);
     P.w2_off = (int)conv_main_lds(L);
-    if (L.tail_cout > 0 && (!conv_tail_supported(L.ks, L.MF, L.NF, L.cout, L.tail_cout) || !L.tail_wpk || !L.tail_bias || !L.tail_out.p)) return hipErrorInvalidValue;
+    if (L.tail_cout > 0 && (!conv_tail_supported(L.ks, L.MF, L.NF, L.cout, L.tail_cout, L.tail_act16) || !L.tail_wpk || !L.tail_bias || (!L.tail_act16 && !L.tail_out.p))) return hipErrorInvalidValue;
 
     int cin_eff = L.in_u8 ? 8 : L.cin;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;

@@ -229,6 +229,19 @@ struct Builder {
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2);
     }
 
+    // true if the 1x1 conv `tail_name` (with activation, 16-bit output) can run inside the launch of its only producer `name`
+    // (a 3x3 conv holding all of its output channels in one workgroup): stride-2 backbone conv -> cv1 of the next C3k2 block
+    bool tail16_ok(const std::string &name, const std::string &tail_name, int Hin, int Win) {
+        const bool on = !(getenv("OBB_TAIL16") && atoi(getenv("OBB_TAIL16")) == 0);
+        if (!M.tail || !on) return false;
+        const ConvRecord *r = rec(name), *r2 = rec(tail_name);
+        if (!r || !r2 || err) return false;
+        if (r->g != 1 || r2->g != 1 || r->k != 3 || r2->k != 1 || r2->s != 1 || !r2->act || !r->act || r2->c1 != r->c2) return false;
+        int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
+        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo);
+        return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true);
+    }
+
     void conv(const std::string &name, Slice in, int Hin, int Win, Slice out, Slice res = Slice(), int head_level = -1,
               const int *perm = nullptr, const char *tail_name = nullptr) {
         const ConvRecord *r = rec(name);
@@ -287,7 +300,13 @@ struct Builder {
         if (tail_name) {  // fused trailing 1x1: `out` is the head slice of the TAIL's output; this layer's own output is never written
             const ConvRecord *r2 = rec(tail_name);
             if (!r2 || err) return;
-            const int nf2 = r2->c2 <= 16 ? 1 : 4;
+            const bool act16 = r2->act != 0;  // cv1 of a C3k2 block: SiLU, 16-bit output of its own in `out`
+            const int nf2 = r2->c2 <= 16 ? 1 : (act16 && r2->c2 <= 32 ? 2 : 4);
+            if (act16 && (r2->c2 != out.C || head_level >= 0)) {
+                err = set_error(ctx, OBB_ERR_STATE, "fused cv1 %s: output slice does not match", tail_name);
+                return;
+            }
+            L.tail_act16 = act16;
             ConvTiling t2{1, 1, 1, nf2, r->c2};
             L.tail_wpk = upload(pack_conv_weights(r2->w, r2->c2, r->c2, 1, t2, nullptr, 0, M.f16));
             std::vector<float> b2(((size_t)r2->c2 + 63) / 64 * 64 + 64, 0.f);
@@ -297,6 +316,7 @@ struct Builder {
             op.name = name + "+" + tail_name;
             P.macs_per_img += (double)op.Ho * op.Wo * r2->c2 * r->c2;
             P.ops.push_back(op);
+            if (act16) P.named[tail_name] = out;
             return;
         }
         P.ops.push_back(op);
@@ -465,14 +485,26 @@ struct Builder {
         conv(name + ".cv3", whole(cat), H, W, out);
     }
 
-    void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e) {
+    // `prod` (optional): the conv whose only consumer is this block, not yet emitted, reading `pin` (pH x pW): if the pair has a
+    // kernel (tail16_ok) this block's cv1 runs inside the producer's launch and the producer's output tensor never exists
+    void c3k2(int li, Slice in, int H, int W, Slice out, int n, bool use_c3k, double e, const char *prod = nullptr, Slice pin = Slice(), int pH = 0,
+              int pW = 0) {
         std::string name = "model." + std::to_string(li);
         int c = (int)(out.C * e);
+        if (prod) {
+            int cat = buf(H, W, (2 + n) * c, name + ".cat", false, use_c3k ? 0 : c);
+            conv(prod, pin, pH, pW, sub(cat, 0, 2 * c), Slice(), -1, nullptr, (name + ".cv1").c_str());
+            c3k2_rest(name, cat, c, H, W, out, n, use_c3k);
+            return;
+        }
         if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !(out.buf >= 0 && P.bufs[out.buf].blk) && fused_c3k2(name, in, H, W, out, e)) return;
         if (err) return;
         // [y0 | y1 | y2 ...]: the bottleneck reads / writes single members of this concat -> one dense block per member
         int cat = buf(H, W, (2 + n) * c, name + ".cat", false, use_c3k ? 0 : c);
         conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
+        c3k2_rest(name, cat, c, H, W, out, n, use_c3k);
+    }
+    void c3k2_rest(const std::string &name, int cat, int c, int H, int W, Slice out, int n, bool use_c3k) {
         for (int i = 0; i < n; ++i) {
             Slice src = sub(cat, (1 + i) * c, c), dst = sub(cat, (2 + i) * c, c);
             if (use_c3k) c3k(name + ".m." + std::to_string(i), src, H, W, dst, 2);
@@ -685,13 +717,16 @@ struct Builder {
 
         int b0 = buf(H2, W2, c64, "x0");
         conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
-        int b1 = buf(H4, W4, c128, "x1");
-        conv("model.1", whole(b0), H2, W2, whole(b1));
+        const bool t1 = tail16_ok("model.1", "model.2.cv1", H2, W2), t3 = tail16_ok("model.3", "model.4.cv1", H4, W4);
+        int b1 = t1 ? -1 : buf(H4, W4, c128, "x1");
+        if (!t1) conv("model.1", whole(b0), H2, W2, whole(b1));
         int b2 = buf(H4, W4, c256, "x2", false, 16);  // consumed by a 3x3 stride-2 conv in 16-channel stages
-        c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
-        int b3 = buf(H8, W8, c256, "x3");
-        conv("model.3", whole(b2), H4, W4, whole(b3));
-        c3k2(4, whole(b3), H8, W8, x4, n2, big, 0.25);
+        if (t1) c3k2(2, Slice(), H4, W4, whole(b2), n2, big, 0.25, "model.1", whole(b0), H2, W2);
+        else c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
+        int b3 = t3 ? -1 : buf(H8, W8, c256, "x3");
+        if (!t3) conv("model.3", whole(b2), H4, W4, whole(b3));
+        if (t3) c3k2(4, Slice(), H8, W8, x4, n2, big, 0.25, "model.3", whole(b2), H4, W4);
+        else c3k2(4, whole(b3), H8, W8, x4, n2, big, 0.25);
         int b5 = buf(H16, W16, c512, "x5");
         conv("model.5", x4, H8, W8, whole(b5));
         c3k2(6, whole(b5), H16, W16, x6, n2, true, 0.5);

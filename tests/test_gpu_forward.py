@@ -132,6 +132,27 @@ def test_concurrent_chains_and_rounds_match_small_batches(ops, net_n):
     assert torch.equal(big, small) and torch.equal(big2, small)
 
 
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (416, 288, 2), (128, 128, 4)])
+def test_cv1_behind_stride2_conv(ops, net_n, h, w, B, monkeypatch):
+    """model.1 / model.3 (3x3 stride 2) run the cv1 of the following C3k2 block on their staged output tile (their own output tensor
+    is never written): same 16-bit rounding of the intermediate, same k order -> identical activations and head."""
+    x = torch.as_tensor(_tiles(23 + h, B, h, w)).cuda()
+    monkeypatch.setenv("OBB_TAIL16", "0")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert not any("+model.2.cv1" in l for l in ops.debug_plan(h, w))
+    ref_head = ops.forward(x).clone()
+    ref = {n: ops.debug_activation(n, B, h, w).clone() for n in ("model.2.cv1", "model.4.cv1")}
+    monkeypatch.delenv("OBB_TAIL16")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    plan = ops.debug_plan(h, w)
+    fused = [l for l in plan if "model.1+model.2.cv1" in l or "model.3+model.4.cv1" in l]
+    assert len(fused) == (2 if (h, w) == (416, 416) else 0), plan   # 13x13 output tiles only (every level of a full 416-px tile)
+    head = ops.forward(x)
+    for n, r in ref.items():
+        assert torch.equal(ops.debug_activation(n, B, h, w), r), n
+    assert torch.equal(head[..., :77], ref_head[..., :77])
+
+
 def test_c3k_image_kernel(ops, net_n, monkeypatch):
     """Inner C3k of the stride-32 level as one persistent workgroup per image (c3kimg.hip) vs the same block as separate launches
     (identical inputs: only this block's implementation differs).  Same rounding points; the 3x3 convs sum all 64 input channels in one

@@ -378,13 +378,16 @@ struct Builder {
         return nm;
     }
 
-    void bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e) {
+    // cv2name (optional): the closing 1x1 of the surrounding C3k2 block (over [y0 | in | out] of the concat buffer -> cv2out); returns
+    // true if that conv was fused behind the Bottleneck (the caller then must not emit it)
+    bool bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e, const char *cv2name = nullptr, Slice y0 = Slice(),
+                    Slice cv2out = Slice()) {
         int c_ = (int)(out.C * e);
         const bool bneck_on = !(getenv("OBB_BNECK") && atoi(getenv("OBB_BNECK")) == 0);
         if (bneck_on && M.bneck && in.buf >= 0 && in.buf == out.buf && P.bufs[in.buf].blk == in.C && in.C == out.C && c_ * 2 == in.C &&
             bneck_supported(in.C, H, W)) {
             const ConvRecord *r1 = rec(name + ".cv1"), *r2 = rec(name + ".cv2");
-            if (!r1 || !r2 || err) return;
+            if (!r1 || !r2 || err) return false;
             if (r1->k == 3 && r2->k == 3 && r1->s == 1 && r2->s == 1 && r1->g == 1 && r2->g == 1 && r1->act && r2->act && r1->c1 == in.C &&
                 r1->c2 == c_ && r2->c1 == c_ && r2->c2 == in.C) {
                 Op op;
@@ -399,15 +402,35 @@ struct Builder {
                 for (int c = 0; c < in.C; ++c) b2[c] = r2->b[c];
                 L.bias1 = upload(b1); L.bias2 = upload(b2);
                 op.macs = (double)H * W * 9.0 * in.C * c_ * 2;
+                bool fused_cv2 = false;
+                const ConvRecord *rc = cv2name ? rec(cv2name) : nullptr;
+                const bool cv2_on = !(getenv("OBB_BNECK_CV2") && atoi(getenv("OBB_BNECK_CV2")) == 0);
+                if (rc && cv2_on && rc->k == 1 && rc->s == 1 && rc->g == 1 && rc->act && rc->c1 == 3 * in.C && rc->c2 == cv2out.C && cv2out.buf >= 0 &&
+                    !P.bufs[cv2out.buf].virt && y0.buf == in.buf && y0.C == in.C && y0.co + in.C == in.co && in.co + in.C == out.co &&
+                    bneck_cv2_supported(in.C, rc->c2)) {
+                    ConvTiling tc{1, 1, 1, rc->c2 / 16, in.C == 32 ? 96 : 32};
+                    L.CO = rc->c2;
+                    L.wc32pk = upload(pack_conv_weights(rc->w, rc->c2, rc->c1, 1, tc, nullptr, 0, M.f16));
+                    if (in.C == 16) L.wc16pk = upload(pack_bneck_k16(rc->w, rc->c2, rc->c1, 32, M.f16));
+                    std::vector<float> bc(128 + 64, 0.f);
+                    for (int c = 0; c < rc->c2; ++c) bc[c] = rc->b[c];
+                    L.biasc = upload(bc);
+                    op.name = name + "+" + cv2name;
+                    op.out = cv2out; op.res = y0;  // res carries the y0 slice to the launch
+                    op.macs += (double)H * W * rc->c1 * rc->c2;
+                    fused_cv2 = true;
+                }
                 P.macs_per_img += op.macs;
                 P.ops.push_back(op);
-                P.named[name + ".cv2"] = out;
-                return;
+                if (fused_cv2) P.named[cv2name] = cv2out;
+                else P.named[name + ".cv2"] = out;
+                return fused_cv2;
             }
         }
         int t = buf(H, W, c_, name + ".t");
         conv(name + ".cv1", in, H, W, whole(t));
         conv(name + ".cv2", whole(t), H, W, out, in);  // shortcut add (c1 == c2)
+        return false;
     }
 
     void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
@@ -505,6 +528,8 @@ struct Builder {
         c3k2_rest(name, cat, c, H, W, out, n, use_c3k);
     }
     void c3k2_rest(const std::string &name, int cat, int c, int H, int W, Slice out, int n, bool use_c3k) {
+        if (n == 1 && !use_c3k && bottleneck(name + ".m.0", sub(cat, c, c), H, W, sub(cat, 2 * c, c), 0.5, (name + ".cv2").c_str(), sub(cat, 0, c), out)) return;
+        if (n == 1 && !use_c3k) { conv(name + ".cv2", whole(cat), H, W, out); return; }
         for (int i = 0; i < n; ++i) {
             Slice src = sub(cat, (1 + i) * c, c), dst = sub(cat, (2 + i) * c, c);
             if (use_c3k) c3k(name + ".m." + std::to_string(i), src, H, W, dst, 2);
@@ -985,7 +1010,10 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
             }
             case OP_BNECK: {
                 BneckLaunch L = op.bneck;
-                L.B = B; L.y1 = tref(P, op.in, boff); L.y2 = tref(P, op.out, boff);
+                L.B = B; L.y1 = tref(P, op.in, boff);
+                if (L.CO > 0) {  // closing 1x1 fused: y2 stays in registers; op.out is the block's output, op.res the y0 member
+                    L.y2 = L.y1; L.y0 = tref(P, op.res, boff); L.out = tref(P, op.out, boff);
+                } else L.y2 = tref(P, op.out, boff);
                 e = launch_bneck(L, st);
                 break;
             }
@@ -1202,7 +1230,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
             case OP_C3KIMG: snprintf(line, sizeof line, "c3kimg %s c%d out%dx%d macs%.0f\n", op.name.c_str(), op.in.C, op.Ho, op.Wo, op.macs); break;
-            case OP_BNECK: snprintf(line, sizeof line, "bneck %s c%d out%dx%d rows4 macs%.0f\n", op.name.c_str(), op.bneck.C, op.Ho, op.Wo, op.macs); break;
+            case OP_BNECK: snprintf(line, sizeof line, "bneck %s c%d co%d out%dx%d rows4 macs%.0f\n", op.name.c_str(), op.bneck.C, op.bneck.CO, op.Ho, op.Wo, op.macs); break;
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;

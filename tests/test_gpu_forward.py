@@ -174,13 +174,14 @@ def test_c3k_image_kernel(ops, net_n, monkeypatch):
         assert float(d.mean()) < (1e-3 if net_n.prec == "f16" else 1e-2) and float(d.max()) < (0.05 if net_n.prec == "f16" else 0.4)
 
 
-def test_fused_bottleneck_stripes(ops, net_n):
+def test_fused_bottleneck_stripes(ops, net_n, monkeypatch):
     """Bottleneck(3x3, 3x3, shortcut) of the 104 / 52 levels as one stripe kernel: same rounding points as the two separate convs.
     The 16 -> 8 -> 16 block also sums in the same order (bit-identical); the 32 -> 16 -> 32 block sums all 32 input channels in one
     k loop where the separate kernel uses two channel stages: rare 1-ulp flips of 16-bit values."""
     B, h, w = 3, 416, 416
     x = torch.as_tensor(_tiles(91, B, h, w)).cuda()
     ref = {}
+    monkeypatch.setenv("OBB_BNECK_CV2", "0")  # keep y2 observable: the closing 1x1 as its own launch (fused form: next test)
     ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=False)
     head_ref = ops.forward(x).clone()
     for name in ("model.2.m.0.cv2", "model.4.m.0.cv2", "model.16.m.0.cv2"):
@@ -200,6 +201,39 @@ def test_fused_bottleneck_stripes(ops, net_n):
             assert float(d.mean()) < (5e-3 if net_n.prec == "f16" else 5e-2) and float(d.max()) < (0.25 if net_n.prec == "f16" else 1.5)
         else:
             assert float((d / ref[name].abs().clamp_min(1.0)).max()) <= 4 * ulp and float((d > 0).float().mean()) < 0.05
+    dh = (head[..., :77] - head_ref[..., :77]).abs()
+    assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), float(dh.mean())
+
+
+def test_closing_1x1_behind_the_bottleneck(ops, net_n, monkeypatch):
+    """C3k2 blocks 2, 4 and 16: cv2 over [y0 | y1 | y2] runs on every 16-pixel fragment right behind the Bottleneck's second conv
+    (y0 from global memory, y1 from the LDS image, y2 from the producing lane's registers).  Same 16-bit rounding of y2; the k sum is
+    split differently from the stand-alone 1x1 (and uses a 16-wide MFMA step for the 16-channel block): 1-ulp flips of 16-bit outputs."""
+    B, h, w = 3, 416, 416
+    x = torch.as_tensor(_tiles(37, B, h, w)).cuda()
+    names = ("model.2.cv2", "model.4.cv2", "model.16.cv2")
+    monkeypatch.setenv("OBB_BNECK_CV2", "0")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert not any(l.startswith("bneck ") and "+model." in l for l in ops.debug_plan(h, w))
+    head_ref = ops.forward(x).clone()
+    ref = {n: ops.debug_activation(n, B, h, w).clone() for n in names}
+    monkeypatch.delenv("OBB_BNECK_CV2")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    plan = ops.debug_plan(h, w)
+    assert sum(l.startswith("bneck ") and ".m.0+model." in l for l in plan) == 3, plan
+    assert not any(l.startswith("conv model.2.cv2 ") or l.startswith("conv model.4.cv2 ") or l.startswith("conv model.16.cv2 ") for l in plan)
+    head = ops.forward(x)
+    ulp = 2.0 ** -10 if net_n.prec == "f16" else 2.0 ** -7
+    for n in names:
+        got = ops.debug_activation(n, B, h, w)
+        assert got.shape == ref[n].shape
+        d = (got - ref[n]).abs()
+        print(n, tuple(got.shape), float(d.max()), float((d > 0).float().mean()))
+        if n == "model.16.cv2":  # its input already carries the propagated flips of the earlier blocks
+            assert float(d.mean()) < (5e-3 if net_n.prec == "f16" else 5e-2) and float(d.max()) < (0.25 if net_n.prec == "f16" else 1.5)
+        else:
+            # (model.4 sees model.2's few flipped inputs on top of its own)
+            assert float((d / ref[n].abs().clamp_min(1.0)).max()) <= 4 * ulp and float((d > 0).float().mean()) < (0.01 if n == "model.2.cv2" else 0.15)
     dh = (head[..., :77] - head_ref[..., :77]).abs()
     assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), float(dh.mean())
 

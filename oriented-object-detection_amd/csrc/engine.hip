@@ -1163,7 +1163,7 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     int rc = get_plan(ctx, h, w, &P);
     if (rc) return rc;
     // The batch is walked in sub-batches: bounds the activation slab (and keeps every 1-D launch inside 32-bit buffer offsets)
-    static const int max_mb = getenv("OBB_MICROBATCH") ? std::max(1, atoi(getenv("OBB_MICROBATCH"))) : 512;  // measured: 128 / 256 / 512 / 1024 -> 67 / 79 / 84 / 83 k tiles/s at B = 1024
+    static const int max_mb = getenv("OBB_MICROBATCH") ? std::max(1, atoi(getenv("OBB_MICROBATCH"))) : 1024;  // measured at B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s (128 / 256: 67 / 79 k with the round-1 kernels)
     rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
     static const bool use_graph = !(getenv("OBB_GRAPH") && atoi(getenv("OBB_GRAPH")) == 0);

@@ -122,7 +122,7 @@ def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B, monkeypatch)
 def test_concurrent_chains_and_rounds_match_small_batches(ops, net_n):
     """A large batch is walked in rounds, each issued as two concurrent half-batch chains that address their own image range of every
     activation buffer (plain, channel-blocked and virtual-concat ones alike): the result must equal the same tiles run in small calls."""
-    B = 600  # rounds of 512 + 88 tiles, both split into two chains
+    B = 1100  # rounds of 1024 + 76 tiles, both split into two chains
     x = torch.as_tensor(_tiles(5, B, 128, 128)).cuda()
     ops.model_load(net_n.to_blob(), precision=net_n.prec)
     big = ops.forward(x).clone()

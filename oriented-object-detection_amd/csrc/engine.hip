@@ -16,6 +16,7 @@
 #include "bneck.h"
 #include "c3kimg.h"
 #include "ctx.h"
+#include "dwpw.h"
 #include "fused.h"
 #include "nnops.h"
 #include "stem.h"
@@ -44,7 +45,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG };
+enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
 
 struct Op {
     OpType type;
@@ -57,6 +58,7 @@ struct Op {
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
     C3kImgLaunch c3kimg;     // OP_C3KIMG (inner C3k of the stride-32 level, one persistent workgroup per image)
+    DwPwLaunch dwpw;         // OP_DWPW (depthwise 3x3 -> 1x1 [-> plain 1x1 to the head] over row stripes)
     double macs = 0;         // OP_FUSED: MACs of all fused layers
     bool one_d = false;
     bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
@@ -345,6 +347,51 @@ struct Builder {
         P.macs_per_img += (double)H * W * C * 9;
         P.ops.push_back(op);
         P.named[name] = out;
+    }
+
+    // DWConv 3x3 `dwname` -> Conv 1x1 `pwname` [-> plain 1x1 `tailname` into the head tensor] as one stripe kernel (dwpw.hip).
+    // Returns false (nothing emitted) if the shapes have no kernel.
+    bool dwpw(const std::string &dwname, const std::string &pwname, Slice in, int H, int W, Slice out, const char *tailname = nullptr, int head_level = -1) {
+        const bool on = M.tail && !(getenv("OBB_DWPW") && atoi(getenv("OBB_DWPW")) == 0);
+        const ConvRecord *rd = rec(dwname), *rp = rec(pwname), *rt = tailname ? rec(tailname) : nullptr;
+        if (!on || !rd || !rp || (tailname && !rt) || err) return false;
+        if (in.buf < 0 || P.bufs[in.buf].blk || P.bufs[in.buf].virt || rd->g != rd->c1 || rd->c1 != rd->c2 || rd->k != 3 || rd->s != 1 || rd->c1 != in.C || !rd->act ||
+            rp->g != 1 || rp->k != 1 || rp->s != 1 || !rp->act || rp->c1 != in.C)
+            return false;
+        if (rt && (rt->g != 1 || rt->k != 1 || rt->s != 1 || rt->act || rt->c1 != rp->c2 || head_level < 0)) return false;
+        if (!rt && (out.buf < 0 || P.bufs[out.buf].blk || P.bufs[out.buf].virt || out.C != rp->c2)) return false;
+        if (!dwpw_supported(in.C, rp->c2, H, W, rt ? rt->c2 : 0)) return false;
+        const int C = in.C;
+        Op op;
+        op.type = OP_DWPW; op.name = dwname + "+" + pwname + (rt ? std::string("+") + tailname : std::string()); op.in = in; op.out = out;
+        op.H = H; op.W = W; op.Ho = H; op.Wo = W; op.head_level = rt ? head_level : -1;
+        DwPwLaunch &L = op.dwpw;
+        L.H = H; L.W = W; L.cin = C; L.f16 = M.f16;
+        std::vector<bf16_t> w((size_t)9 * C + 8, 0);
+        std::vector<float> b((size_t)C + 8, 0.f);
+        for (int c = 0; c < C; ++c) {
+            for (int t = 0; t < 9; ++t) w[(size_t)t * C + c] = host_to_half(rd->w[(size_t)c * 9 + t], M.f16);
+            b[c] = rd->b[c];
+        }
+        L.dw_w = upload(w); L.dw_b = upload(b);
+        ConvTiling tp{1, 1, 1, 4, C};
+        L.pw_w = upload(pack_conv_weights(rp->w, rp->c2, C, 1, tp, nullptr, 0, M.f16));
+        std::vector<float> pb(64 + 64, 0.f);
+        for (int c = 0; c < rp->c2; ++c) pb[c] = rp->b[c];
+        L.pw_b = upload(pb);
+        op.macs = (double)H * W * (9.0 * C + (double)C * rp->c2);
+        if (rt) {
+            L.tail_cout = rt->c2;
+            L.tail_w = upload(pack_dwpw_tail(rt->w, rt->c2, M.f16));
+            std::vector<float> tb(64, 0.f);
+            for (int c = 0; c < rt->c2; ++c) tb[c] = rt->b[c];
+            L.tail_b = upload(tb);
+            op.macs += (double)H * W * rt->c1 * rt->c2;
+        }
+        P.macs_per_img += op.macs;
+        P.ops.push_back(op);
+        if (!rt) P.named[pwname] = out;
+        return true;
     }
 
     void pool(Slice in, int H, int W, Slice out) {
@@ -867,10 +914,19 @@ struct Builder {
             std::string p = "model.23.cv3." + std::to_string(i);
             if (M.fuse && fused_head_cls(p, whole(feats[i]), Hs[i], Ws[i], c3, i)) continue;
             if (err) return err;
-            int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1"), e1 = buf(Hs[i], Ws[i], c3, p + ".e1"), d2 = buf(Hs[i], Ws[i], c3, p + ".d2"),
-                e2 = buf(Hs[i], Ws[i], c3, p + ".e2");
-            dwconv(p + ".0.0", whole(feats[i]), Hs[i], Ws[i], whole(d1));
-            conv(p + ".0.1", whole(d1), Hs[i], Ws[i], whole(e1));
+            int e1 = buf(Hs[i], Ws[i], c3, p + ".e1");
+            if (!dwpw(p + ".0.0", p + ".0.1", whole(feats[i]), Hs[i], Ws[i], whole(e1))) {
+                int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1");
+                dwconv(p + ".0.0", whole(feats[i]), Hs[i], Ws[i], whole(d1));
+                conv(p + ".0.1", whole(d1), Hs[i], Ws[i], whole(e1));
+            }
+            if (err) return err;
+            if (dwpw(p + ".1.0", p + ".1.1", whole(e1), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, (p + ".2").c_str(), i)) {
+                mark_branch(first_op, 2, i);
+                continue;
+            }
+            if (err) return err;
+            int d2 = buf(Hs[i], Ws[i], c3, p + ".d2"), e2 = buf(Hs[i], Ws[i], c3, p + ".e2");
             dwconv(p + ".1.0", whole(e1), Hs[i], Ws[i], whole(d2));
             if (tail_ok(p + ".1.1", p + ".2", Hs[i], Ws[i])) {
                 conv(p + ".1.1", whole(d2), Hs[i], Ws[i], Slice{-2, 4 * kRegMax, M.nc}, Slice(), i, nullptr, (p + ".2").c_str());
@@ -1006,6 +1062,18 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 C3kImgLaunch L = op.c3kimg;
                 L.B = B; L.in = tref(P, op.in, boff); L.out = tref(P, op.out, boff);
                 e = launch_c3kimg(L, st);
+                break;
+            }
+            case OP_DWPW: {
+                DwPwLaunch L = op.dwpw;
+                L.B = B; L.in = tref(P, op.in, boff);
+                if (op.head_level >= 0) {
+                    TensorRef hr;
+                    hr.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    hr.bs = (int64_t)P.A * P.no_pad; hr.cs = P.no_pad; hr.co = op.out.co;
+                    L.tail_out = hr;
+                } else L.out = tref(P, op.out, boff);
+                e = launch_dwpw(L, st);
                 break;
             }
             case OP_BNECK: {
@@ -1230,6 +1298,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;
                 snprintf(line, sizeof line, "%s %s c%d out%dx%d macs%.0f\n", ty, op.name.c_str(), op.in.C, op.Ho, op.Wo, macs); break;
             case OP_C3KIMG: snprintf(line, sizeof line, "c3kimg %s c%d out%dx%d macs%.0f\n", op.name.c_str(), op.in.C, op.Ho, op.Wo, op.macs); break;
+            case OP_DWPW: snprintf(line, sizeof line, "dwpw %s c%d tail%d out%dx%d macs%.0f\n", op.name.c_str(), op.dwpw.cin, op.dwpw.tail_cout, op.Ho, op.Wo, op.macs); break;
             case OP_BNECK: snprintf(line, sizeof line, "bneck %s c%d co%d out%dx%d rows4 macs%.0f\n", op.name.c_str(), op.bneck.C, op.bneck.CO, op.Ho, op.Wo, op.macs); break;
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;

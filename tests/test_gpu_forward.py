@@ -153,6 +153,32 @@ def test_cv1_behind_stride2_conv(ops, net_n, h, w, B, monkeypatch):
     assert torch.equal(head[..., :77], ref_head[..., :77])
 
 
+def test_depthwise_pointwise_stripes(ops, net_n, monkeypatch):
+    """Class branch of the head at the 52 / 26 levels: DWConv 3x3 -> Conv 1x1 (-> plain 1x1 into the head tensor) as one stripe kernel
+    per pair, the depthwise result living only in registers as the MFMA operand.  Same arithmetic and rounding points as the separate
+    kernels for the first pair (identical activations); the trailing 1x1 sums its 64 inputs in a different k order (fp32: ~1e-6)."""
+    B, h, w = 3, 416, 416
+    x = torch.as_tensor(_tiles(71, B, h, w)).cuda()
+    names = ("model.23.cv3.0.0.1", "model.23.cv3.1.0.1")
+    monkeypatch.setenv("OBB_DWPW", "0")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert not any(l.startswith("dwpw ") for l in ops.debug_plan(h, w))
+    head_ref = ops.forward(x).clone()
+    ref = {n: ops.debug_activation(n, B, h, w).clone() for n in names}
+    monkeypatch.delenv("OBB_DWPW")
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    plan = ops.debug_plan(h, w)
+    assert sum(l.startswith("dwpw ") for l in plan) == 4, plan
+    assert sum(l.startswith("dwconv model.23.cv3.") for l in plan) == 2, plan   # the 13x13 level keeps the separate kernels
+    head = ops.forward(x)
+    for n in names:
+        assert torch.equal(ops.debug_activation(n, B, h, w), ref[n]), n
+    d = (head[..., :77] - head_ref[..., :77]).abs()
+    assert float(d[..., :64].max()) == 0.0 and float(d[..., 76].max()) == 0.0   # box and angle branches untouched
+    print("class logits: max diff", float(d[..., 64:76].max()))
+    assert float(d[..., 64:76].max()) <= 2e-5
+
+
 def test_c3k_image_kernel(ops, net_n, monkeypatch):
     """Inner C3k of the stride-32 level as one persistent workgroup per image (c3kimg.hip) vs the same block as separate launches
     (identical inputs: only this block's implementation differs).  Same rounding points; the 3x3 convs sum all 64 input channels in one

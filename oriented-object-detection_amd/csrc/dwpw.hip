@@ -57,6 +57,16 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
         int r = i / (2 * (XP / 16)), rem = i - r * (2 * (XP / 16)), side = rem / (XP / 16), c = rem - side * (XP / 16);
         *reinterpret_cast<u32x4 *>(X + (r * XW + (side ? W + 1 : 0)) * XP + c * 16) = u32x4{0u, 0u, 0u, 0u};
     }
+    // depthwise weights of this lane's chunks in registers when they fit (64 input channels: 2 k steps x 9 taps x 16 B): the stripe
+    // loop's barriers would otherwise force an LDS re-read per fragment
+    constexpr bool DWREG = false;  // (measured: 72 weight registers push the 52-wide variants into spills)
+    u32x4 dwr[DWREG ? KS : 1][DWREG ? 9 : 1];
+    if constexpr (DWREG) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dwr[ks][t] = *reinterpret_cast<const u32x4 *>(P.dww + t * CIN + (ks * 4 + g) * 8);
+    }
     __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8));  // vmcnt(0): settle the weight / bias loads outside the stripe loop
 
     // input chunks of this thread: idx = tid + k*256 -> (row, chunk in row); surplus slots re-read the last chunk into a dummy LDS slot
@@ -114,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const u32x4 xv = *reinterpret_cast<const u32x4 *>(xb + (ky * XW + kx) * XP + q * 16);
-                        const u32x4 wv = *reinterpret_cast<const u32x4 *>(DW + ((ky * 3 + kx) * CIN + q * 8) * 2);
+                        u32x4 wv;
+                        if constexpr (DWREG) wv = dwr[ks][ky * 3 + kx];
+                        else wv = *reinterpret_cast<const u32x4 *>(DW + ((ky * 3 + kx) * CIN + q * 8) * 2);
                         hel xe[8], we[8];
                         __builtin_memcpy(xe, &xv, 16);
                         __builtin_memcpy(we, &wv, 16);
@@ -169,7 +181,10 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static int dwpw_rows(int W) { return W == 52 ? 4 : 2; }
+static int dwpw_rows(int W) {
+    static const int r52 = getenv("OBB_DWPW_R52") ? atoi(getenv("OBB_DWPW_R52")) : 4;
+    return W == 52 ? (r52 == 2 ? 2 : 4) : 2;
+}
 
 bool dwpw_supported(int cin, int cout, int H, int W, int tail_cout) {
     if (cout != 64 || tail_cout < 0 || tail_cout > 16) return false;
@@ -222,6 +237,7 @@ hipError_t launch_dwpw(const DwPwLaunch &L, hipStream_t st) {
     int64_t spw = ns / (256 * 3 * 2);
     P.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, spw_max));
     dim3 grid((unsigned)((ns + P.spw - 1) / P.spw));
+    if (L.W == 52 && R == 2) return L.tail_cout ? launch_t<64, 52, 2, true>(L, P, grid, st) : launch_t<64, 52, 2, false>(L, P, grid, st);
     if (L.W == 52) return L.tail_cout ? launch_t<64, 52, 4, true>(L, P, grid, st) : launch_t<64, 52, 4, false>(L, P, grid, st);
     if (L.cin == 128) return launch_t<128, 26, 2, false>(L, P, grid, st);
     return L.tail_cout ? launch_t<64, 26, 2, true>(L, P, grid, st) : launch_t<64, 26, 2, false>(L, P, grid, st);

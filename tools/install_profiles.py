@@ -7,7 +7,7 @@ shutil.copy(newest(O + "/prof_b/*/*_kernel_stats.csv"), R + "bench_kernel_stats.
 shutil.copy(newest(O + "/prof_bs/*/*_kernel_stats.csv"), R + "bench_kernel_stats_sequential.csv")
 shutil.copy(O + "/bench.json", R + "bench.json")
 shutil.copy(O + "/layers.txt", R + "forward_layers_b256.txt")
-KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_fused", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image")
+KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_fused", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image", "k_dwpw_stripe")
 def load(d):
     plan = [l for l in open(d + "/plan.txt").read().strip().split("\n") if not l.startswith("total")]
     disp = collections.OrderedDict()

@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_TILE = 2 * 1392703312  # YOLO11n-OBB nc=12, 3x416x416
+FLOP_PER_TILE_4CH = 2797866656  # same table, 4-channel input (BASELINE configs[3])
 PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels", type=int, default=3, choices=[3, 4], help="4 = BASELINE configs[3]: every step also builds the RGB + DT-edge "
+                    "input of a 4-channel checkpoint from the BGR tiles (build_multich) before the forward; not the headline configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,10 +102,10 @@ def main():
     from oriented_object_detection_amd.model import YOLO
 
     if rank == 0:
-        wpath = make_weights.ensure("n", 12, 3, 0)
+        wpath = make_weights.ensure("n", 12, args.channels, 0)
     if world > 1:
         dist.barrier()
-    wpath = make_weights.path_for("n", 12, 3, 0)
+    wpath = make_weights.path_for("n", 12, args.channels, 0)
     model = YOLO(wpath, imgsz=416, precision=args.precision)
     cfg = D.Config(tile_sizes=(416,), overlaps=(100,))
     B = args.batch
@@ -117,14 +120,20 @@ def main():
     # Every step still performs all of its work inside the timed region; nothing is reused between steps (heads are double-buffered).
     s_fwd, s_post = torch.cuda.Stream(), torch.cuda.Stream()
     head_bufs = [torch.zeros((B, 3549, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
+    # 4-channel mode: the input builder runs on the forward's stream in front of it (measured: on a stream of its own, under the previous
+    # step's forward, it costs more than it hides -- 70.3 k vs 72.4 k tiles/s: the forward's two chains and the post-processing stream
+    # already occupy the hardware queues)
+    tiles4 = torch.zeros((B, 416, 416, 4), dtype=torch.uint8, device=dev) if args.channels == 4 else None
     md = cfg.max_det
 
     def launch_forward(k, timed):
         with torch.cuda.stream(s_fwd):
             model._ensure_active()
             e0, e1 = torch.cuda.Event(enable_timing=timed), torch.cuda.Event(enable_timing=timed)
+            if tiles4 is not None:
+                ops.build_multich(tiles, out=tiles4)  # inside the step, outside the forward's event pair
             e0.record()
-            head = ops.forward(tiles, out=head_bufs[k % 2])
+            head = ops.forward(tiles if tiles4 is None else tiles4, out=head_bufs[k % 2])
             e1.record()
         if timed:
             fwd_ev.append((e0, e1))
@@ -207,21 +216,25 @@ def main():
 
     if rank == 0:
         tiles_per_s = world * B * args.steps / dt
-        achieved = B * FLOP_PER_TILE / (fwd_ms * 1e-3) / 1e12
+        achieved = B * (FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH) / (fwd_ms * 1e-3) / 1e12
         out = {
-            "metric": "416px tiles/sec (whole node), YOLOv11n-OBB 3ch",
+            "metric": "416px tiles/sec (whole node), YOLOv11n-OBB %dch" % args.channels,
             "value": tiles_per_s, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "f16" else "bf16", "data": "synthetic",
-            "config": {"workload": "YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
-                                   "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge",
+            "config": {"workload": ("YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
+                                    "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge") if args.channels == 3 else
+                                   ("YOLOv11n-OBB 4ch (RGB + DT-edge) 416x416 tiled inference, single-scale (BASELINE configs[3] per GPU): build_multich + "
+                                    "forward + decode + ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge"),
                        "tiles_per_gpu_per_step": B, "step_pipelining": bool(args.pipeline), "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
                        "survivor_records_per_step": nrec, "final_detections": nmerged},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": profiled_traffic(), "traffic_source": "profiles/r01_forward_hbm_traffic_b256.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "passes of this build, bytes per tile x tiles per step)", "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.channels == 4:
+            out["roofline"]["traffic"] = None  # the committed PMC passes are of the 3-channel forward
+        if not args.no_cpu_baseline and world == 1 and args.channels == 3:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -71,11 +71,15 @@ def poly_iou_matrix(a, b, cls_a=None, cls_b=None):
     return out
 
 
-def build_multich(bgr_tiles):
+def build_multich(bgr_tiles, out=None):
     """uint8 [B,h,w,3] BGR crops -> uint8 [B,h,w,4] = RGB + distance-transform edge channel (Detect_OBB.py:87-133)"""
     t = _chk(bgr_tiles, torch.uint8, "bgr_tiles")
     assert t.dim() == 4 and t.shape[3] == 3
-    out = torch.empty((t.shape[0], t.shape[1], t.shape[2], 4), dtype=torch.uint8, device=t.device)
+    if out is None:
+        out = torch.empty((t.shape[0], t.shape[1], t.shape[2], 4), dtype=torch.uint8, device=t.device)
+    else:
+        _chk(out, torch.uint8, "out")
+        assert tuple(out.shape) == (t.shape[0], t.shape[1], t.shape[2], 4)
     _call("obb_build_multich", ctx(t.device), _p(t), t.shape[0], t.shape[1], t.shape[2], _p(out), _stream())
     return out
 

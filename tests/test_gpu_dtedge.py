@@ -53,3 +53,30 @@ def test_build_multich_matches_numpy_restatement(idx):
         e = od.build_multich(im, 4)
         dd = np.abs(got[k, ..., 3].astype(np.int32) - e[..., 3].astype(np.int32))
         assert dd.max() <= 1 and (dd > 0).mean() < 5e-3
+
+
+def test_build_multich_ragged_shapes():
+    """Crops of arbitrary size (ragged border tiles): every pixel-tile / lane-chunk remainder of the six kernels, one batch per shape."""
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import ops
+    rng = np.random.default_rng(11)
+    shapes = [(2, 2), (3, 17), (17, 3), (33, 65), (64, 129), (97, 257), (31, 513), (130, 1024), (200, 70)]
+    for h, w in shapes:
+        base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        smooth = np.clip(np.cumsum(rng.integers(-3, 4, (h, w, 3)), axis=1) + 128, 0, 255).astype(np.uint8)  # few distinct gradients: ties
+        batch = np.stack([base, smooth])
+        got = ops.build_multich(torch.as_tensor(batch).cuda()).cpu().numpy()
+        for k in range(2):
+            exp = od.build_multich(batch[k], 4)
+            d = np.abs(got[k, ..., 3].astype(np.int32) - exp[..., 3].astype(np.int32))
+            assert np.array_equal(got[k, ..., :3], batch[k][..., ::-1])
+            assert d.max() <= 1 and (d > 0).sum() <= max(1, d.size // 200), ((h, w), k, int(d.max()), int((d > 0).sum()))
+
+
+def test_build_multich_rejects_unsupported_sizes():
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.build_multich(torch.zeros((1, 8, 1025, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.build_multich(torch.zeros((1, 1, 8, 3), dtype=torch.uint8, device="cuda"))

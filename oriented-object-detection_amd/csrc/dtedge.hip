@@ -38,20 +38,21 @@ struct DtTaps {
 struct DtStats { double thr, lo, hi; float mn, mx; int pad[2]; };
 
 // BORDER_REFLECT_101 for any offset (cv2's borderInterpolate folds until the index is inside): the extension is even and periodic
-// with period 2 (n - 1); one reflection covers everything a crop of 16+ pixels asks for, the modulo is the rare path.
+// with period 2 (n - 1).  SMALL = false: one reflection, branch-free -- all that a crop of 16+ pixels asks for (7-tap radius + Scharr;
+// cells further out only exist in tiles that overhang the image and feed no valid pixel: clamped).  SMALL = true: the general fold.
+template <bool SMALL>
 __device__ __forceinline__ int reflect_clamp(int i, int n) {
-    int r = i < 0 ? -i : i;
-    if (r >= n) {
-        r = 2 * (n - 1) - r;
-        if (r < 0) {
-            if (n == 1) return 0;
-            const int period = 2 * (n - 1);
-            r = i % period;
-            r = r < 0 ? r + period : r;
-            r = r < n ? r : period - r;
-        }
+    if constexpr (SMALL) {
+        if (n == 1) return 0;
+        const int period = 2 * (n - 1);
+        int r = i % period;
+        r = r < 0 ? r + period : r;
+        return r < n ? r : period - r;
+    } else {
+        int r = i < 0 ? -i : i;
+        r = r >= n ? 2 * (n - 1) - r : r;
+        return min(max(r, 0), n - 1);
     }
-    return r;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ k_dt_acc
@@ -164,6 +165,7 @@ __device__ __forceinline__ void vpass(const unsigned *s_hb, uint8_t *s_bv, const
     }
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_dt_acc(const uint8_t *__restrict__ bgr, int h, int w, float *__restrict__ acc, size_t crop_stride, int pitch,
                                                 DtTaps K) {
     __shared__ unsigned s_g[kGR * kGPD];
@@ -174,12 +176,12 @@ __global__ __launch_bounds__(256) void k_dt_acc(const uint8_t *__restrict__ bgr,
     // ---- grey (8-bit fixed point) of the tile and its halo; reflection happens here, so every later pass is border-free
     for (int q = tid; q < kGR * kGPD; q += 256) {
         const int row = q / kGPD, dq = q - row * kGPD;
-        const int iy = reflect_clamp(y0 - 8 + row, h);
+        const int iy = reflect_clamp<SMALL>(y0 - 8 + row, h);
         unsigned packed = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ix = reflect_clamp(x0 - 12 + dq * 4 + i, w);
-            const uint8_t *p = src + ((size_t)iy * w + ix) * 3;
+            const int ix = reflect_clamp<SMALL>(x0 - 12 + dq * 4 + i, w);
+            const uint8_t *p = src + (iy * w + ix) * 3;  // (h * w * 3 < 2^31: checked by the launcher)
             const unsigned g = ((unsigned)p[0] * 1868u + (unsigned)p[1] * 9617u + (unsigned)p[2] * 4899u + (1u << 13)) >> 14;
             packed |= g << (8 * i);
         }
@@ -703,7 +705,8 @@ extern "C" int obb_build_multich(obb_ctx *ctx, const uint8_t *bgr, int32_t B, in
     for (int i = 0; i < 3; ++i) gauss_taps(sig[i], i, &K);
     hipStream_t st = (hipStream_t)s;
     const dim3 tiles((unsigned)((w + kTW - 1) / kTW), (unsigned)((h + kTH - 1) / kTH), (unsigned)B);
-    hipLaunchKernelGGL(k_dt_acc, tiles, dim3(256), 0, st, bgr, h, w, acc, acc_stride, pitch, K);
+    if (h < 16 || w < 16) hipLaunchKernelGGL(k_dt_acc<true>, tiles, dim3(256), 0, st, bgr, h, w, acc, acc_stride, pitch, K);
+    else hipLaunchKernelGGL(k_dt_acc<false>, tiles, dim3(256), 0, st, bgr, h, w, acc, acc_stride, pitch, K);
     hipLaunchKernelGGL(k_dt_select<1>, dim3((unsigned)B), dim3(kSelThreads), 0, st, acc, acc_stride, h, w, pitch, stats, 90.0, 0.0);  // DT_P_HI (Detect_OBB.py:31)
     hipLaunchKernelGGL(k_dt_edges, tiles, dim3(256), 0, st, acc, acc_stride, h, w, pitch, stats, edges, edge_bytes);
     switch (px) {

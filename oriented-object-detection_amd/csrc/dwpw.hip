@@ -127,11 +127,7 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
                         u32x4 wv;
                         if constexpr (DWREG) wv = dwr[ks][ky * 3 + kx];
                         else wv = *reinterpret_cast<const u32x4 *>(DW + ((ky * 3 + kx) * CIN + q * 8) * 2);
-                        hel xe[8], we[8];
-                        __builtin_memcpy(xe, &xv, 16);
-                        __builtin_memcpy(we, &wv, 16);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) a8[j] = __builtin_fmaf((float)xe[j], (float)we[j], a8[j]);
+                        fma8_mixed<F16>(a8, uint4{xv.x, xv.y, xv.z, xv.w}, uint4{wv.x, wv.y, wv.z, wv.w});
                     }
                 const float4 b0 = *reinterpret_cast<const float4 *>(s_dwb + q * 8), b1 = *reinterpret_cast<const float4 *>(s_dwb + q * 8 + 4);
                 u32x4 du;
@@ -182,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
 // ------------------------------------------------------------------------------------------------ host side
 
 static int dwpw_rows(int W) {
-    static const int r52 = getenv("OBB_DWPW_R52") ? atoi(getenv("OBB_DWPW_R52")) : 4;
-    return W == 52 ? (r52 == 2 ? 2 : 4) : 2;
+    static const int r52 = getenv("OBB_DWPW_R52") ? atoi(getenv("OBB_DWPW_R52")) : 2;  // measured: 2-row stripes (41 KB of LDS, three groups per CU) 99.6 k vs 4-row 98.9 k tiles/s
+    return W == 52 ? (r52 == 4 ? 4 : 2) : 2;
 }
 
 bool dwpw_supported(int cin, int cout, int H, int W, int tail_cout) {

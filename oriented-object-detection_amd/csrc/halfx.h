@@ -65,6 +65,23 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
     return make_uint4(HX<F16>::pack2(f[0], f[1]), HX<F16>::pack2(f[2], f[3]), HX<F16>::pack2(f[4], f[5]), HX<F16>::pack2(f[6], f[7]));
 }
 
+// acc[0..7] += x[0..7] * w[0..7] for two vectors of eight 16-bit values, fp32 accumulate.  fp16: v_fma_mix_f32 reads both halves of a
+// dword directly (no conversion instructions; the compiler otherwise spends two v_cvt_f32_f16 per product); bf16: shifts / masks.
+template <bool F16>
+__device__ __forceinline__ void fma8_mixed(float (&acc)[8], const uint4 &x, const uint4 &w) {
+    const uint32_t xd[4] = {x.x, x.y, x.z, x.w}, wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if constexpr (F16) {
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * d]) : "v"(xd[d]), "v"(wd[d]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * d + 1]) : "v"(xd[d]), "v"(wd[d]));
+        } else {
+            acc[2 * d] = __builtin_fmaf(HX<false>::lo(xd[d]), HX<false>::lo(wd[d]), acc[2 * d]);
+            acc[2 * d + 1] = __builtin_fmaf(HX<false>::hi(xd[d]), HX<false>::hi(wd[d]), acc[2 * d + 1]);
+        }
+    }
+}
+
 // SiLU with the hardware exp and reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp): its error is far below the 16-bit storage rounding
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 

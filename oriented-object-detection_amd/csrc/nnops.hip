@@ -44,7 +44,6 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
     }
     // weights as 16-bit values (what they were rounded to anyway): the products run as mixed-precision FMAs (v_fma_mix_f32 takes
     // the fp16 operands directly, fp32 accumulate), so no conversion instructions are spent on either operand
-    typedef typename HX<F16>::elem hel;
     uint4 wraw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wraw[t] = *reinterpret_cast<const uint4 *>(w16 + t * C + c8 * 8);
@@ -54,20 +53,11 @@ __global__ __launch_bounds__(256) void k_dwconv3(TensorRef in, TensorRef out, Te
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        hel win[6][8];
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) __builtin_memcpy(win[k], &raw[ky][k], 16);
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            hel wv[8];
-            __builtin_memcpy(wv, &wraw[ky * 3 + kx], 16);
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[p][j] = __builtin_fmaf((float)win[p + kx][j], (float)wv[j], acc[p][j]);
-        }
-    }
+            for (int p = 0; p < 4; ++p) fma8_mixed<F16>(acc[p], raw[ky][p + kx], wraw[ky * 3 + kx]);
     const float4 *bp = reinterpret_cast<const float4 *>(bias + c8 * 8);
     float4 b0 = bp[0], b1 = bp[1];
     float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
         }
     }
     const int cbase = cb * 16 * NF + g * 4 * NF;
+    const bool do_act = P.act && !(P.dbg & 4);
 
     // ---- tile bookkeeping: a group walks `tpw` consecutive pixel tiles so that prologue, weight staging (single-stage layers)
     //      and the first activation fetch of the next tile are amortised / overlapped
@@ -350,11 +351,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[mf][f][r] + bias[f * 4 + r];
-                    if (P.act && !(P.dbg & 4)) x = silu_f(x);
-                    v[f * 4 + r] = x;
-                }
+                for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r] + bias[f * 4 + r];
+            if (do_act) {  // one uniform branch around 4*NF independent SiLUs (a test per element serialises the transcendental chains)
+#pragma unroll
+                for (int c = 0; c < NF * 4; ++c) v[c] = silu_f(v[c]);
+            }
             if (P.res) {
                 const bf16_t *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + (int64_t)((cbase >> 3) >> P.res_bsh) * P.res_ps +
                                    (((cbase >> 3) & P.res_bmask) << 3) + (cbase & 7);

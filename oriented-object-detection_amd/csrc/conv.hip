@@ -59,7 +59,9 @@ struct ConvParams {
 // T16: the trailing 1x1 has an activation and a 16-bit (possibly channel-blocked) output of its own -- the cv1 of the C3k2 block behind a
 // stride-2 backbone conv: its result replaces the staged tile in LDS and leaves through the same coalesced write-out.
 template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false>
-__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams P) {
+// Register budget: the 64-cout 3x3 variants need ~210 VGPRs (two waves per SIMD); everything else fits 168 without spills, which is the
+// difference between two and three resident waves per SIMD (allocation granule 8: 170 registers already drop to two).
+__global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2 : 3) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) bf16_t s_lut[IN_U8 ? 256 : 8];  // u8 -> half(v/255); sized in multiples of 16 B (statics precede the dynamic region)

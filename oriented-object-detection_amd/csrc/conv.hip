@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
     }
     const int cbase = cb * 16 * NF + g * 4 * NF;
     const bool do_act = P.act && !(P.dbg & 4);
+    constexpr bool DBUF = NF == 4 && (KS == 3 ? MF >= 2 : MF == 3);  // the two-waves-per-SIMD register class (see __launch_bounds__)
 
     // ---- tile bookkeeping: a group walks `tpw` consecutive pixel tiles so that prologue, weight staging (single-stage layers)
     //      and the first activation fetch of the next tile are amortised / overlapped
@@ -290,10 +291,9 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
             }
 
             // ---- K loop over this stage: weight and activation fragments both come from LDS (ds_read_b128, lane-linear / padded rows)
-            for (int ks = 0; ks < ((P.dbg & 1) ? 0 : P.kst); ++ks) {
-                hx8 wcur[NF];
+            auto ld_operands = [&](int ks, hx8 (&w)[NF], hx8 (&a)[MF]) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f) wcur[f] = *reinterpret_cast<const hx8 *>(wlds + ((ks * NF + f) * 64 + lane) * 16);
+                for (int f = 0; f < NF; ++f) w[f] = *reinterpret_cast<const hx8 *>(wlds + ((ks * NF + f) * 64 + lane) * 16);
                 int q = ks * 4 + g;
                 q = q < nq ? q : nq - 1;  // padding k-steps: any valid address, their weights are zero
                 int off;
@@ -304,13 +304,42 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
                 } else {
                     off = q * 16;
                 }
-                hx8 a[MF];
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const hx8 *>(smem + pixbase[mf] + off);
+            };
+            auto mfma_step = [&](const hx8 (&w)[NF], const hx8 (&a)[MF]) {
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[mf][f] = HX<F16>::mfma(wcur[f], a[mf], acc[mf][f]);
+                    for (int f = 0; f < NF; ++f) acc[mf][f] = HX<F16>::mfma(w[f], a[mf], acc[mf][f]);
+            };
+            const int kst = (P.dbg & 1) ? 0 : P.kst;
+            if constexpr (DBUF) {
+                // two operand sets: the NF + MF LDS reads of step k+1 are issued before the MFMAs of step k (these variants have the
+                // registers: they run two waves per SIMD either way), so the matrix pipe only waits for LDS at the first step of a stage
+                hx8 wA[NF], aA[MF], wB[NF], aB[MF];
+                if (kst > 0) ld_operands(0, wA, aA);
+                for (int ks = 0; ks < kst; ks += 2) {
+                    ld_operands(min(ks + 1, kst - 1), wB, aB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(wA, aA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < kst) {
+                        ld_operands(min(ks + 2, kst - 1), wA, aA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(wB, aB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+                for (int ks = 0; ks < kst; ++ks) {
+                    hx8 wcur[NF], a[MF];
+                    ld_operands(ks, wcur, a);
+                    // all NF + MF operand reads of the k step are in flight before its first MFMA (left alone, the scheduler re-used one
+                    // register quad for the MF activation fragments: read, wait, 4 MFMAs, three times per step)
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(wcur, a);
+                }
             }
         }
         w_resident = (P.nstage == 1);  // single-stage layers keep their weights in LDS for every following tile

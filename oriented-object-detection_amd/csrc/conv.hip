@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
     const int cbase = cb * 16 * NF + g * 4 * NF;
     const bool do_act = P.act && !(P.dbg & 4);
     constexpr bool DBUF = NF == 4 && (KS == 3 ? MF >= 2 : MF == 3);  // the two-waves-per-SIMD register class (see __launch_bounds__)
+    // 64-cout groups store their 16-bit outputs straight from registers: a lane's 16 couts are 32 contiguous bytes and the four lanes of a
+    // pixel a whole 128-B row piece (or one 32-B row of four channel-blocked planes) -- nothing left for an LDS transpose to coalesce
+    constexpr bool DIRECT = NF == 4 && TAIL == 0 && !OUT_F32 && !IN_U8;
 
     // ---- tile bookkeeping: a group walks `tpw` consecutive pixel tiles so that prologue, weight staging (single-stage layers)
     //      and the first activation fetch of the next tile are amortised / overlapped
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
             float4 bv = *reinterpret_cast<const float4 *>(s_bias + g * 4 * NF + f * 4);
             bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
         }
-        if constexpr (!OUT_F32) __syncthreads();  // every wave is done reading the input tile: its LDS becomes the output staging area
+        if constexpr (!OUT_F32 && !DIRECT) __syncthreads();  // every wave is done reading the input tile: its LDS becomes the output staging area
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
@@ -422,6 +425,17 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
 #pragma unroll
                     for (int c = 0; c < NF * 4; ++c)
                         if (cbase + c < P.cout) op[c] = v[c];
+                }
+            } else if constexpr (DIRECT) {
+                bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
+#pragma unroll
+                for (int h = 0; h < NF / 2; ++h) {
+                    uint4 o;
+                    o.x = HX<F16>::pack2(v[h * 8 + 0], v[h * 8 + 1]); o.y = HX<F16>::pack2(v[h * 8 + 2], v[h * 8 + 3]);
+                    o.z = HX<F16>::pack2(v[h * 8 + 4], v[h * 8 + 5]); o.w = HX<F16>::pack2(v[h * 8 + 6], v[h * 8 + 7]);
+                    const int occ = cb * 2 * NF + g * (NF / 2) + h;  // 8-channel chunk index inside the output slice
+                    if (occ * 8 + 8 <= P.cout)
+                        *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = o;
                 }
             } else {  // 16-bit outputs are staged through LDS so that the global stores below are whole 16-B-per-lane row pieces
                 char *orow = smem + ((wave * MF + mf) * 16 + pl) * ROWB + g * 8 * NF;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
                 }
             }
             }
-        } else if constexpr (!OUT_F32) {
+        } else if constexpr (!OUT_F32 && !DIRECT) {
             __syncthreads();
             write_out(std::integral_constant<int, 2 * NF>(), P.cout, cb * 2 * NF);
         }

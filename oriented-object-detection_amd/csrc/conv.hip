@@ -468,12 +468,14 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
                 for (int f = 0; f < TAIL; ++f) w2[f] = *reinterpret_cast<const hx8 *>(smem + P.w2_off + ((ks * TAIL + f) * 64 + lane) * 16);
                 int q = ks * 4 + g;
                 q = q < 2 * NF ? q : 2 * NF - 1;  // k = the 16*NF staged channels; padding chunks carry zero weights
+                hx8 a2[MF];
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) {
-                    hx8 a = *reinterpret_cast<const hx8 *>(smem + ((wave * MF + mf) * 16 + pl) * ROWB + q * 16);
+                for (int mf = 0; mf < MF; ++mf) a2[mf] = *reinterpret_cast<const hx8 *>(smem + ((wave * MF + mf) * 16 + pl) * ROWB + q * 16);
+                __builtin_amdgcn_sched_barrier(0);  // operand reads of the step ahead of its MFMAs (as in the main k loop)
 #pragma unroll
-                    for (int f = 0; f < TAIL; ++f) acc2[mf][f] = HX<F16>::mfma(w2[f], a, acc2[mf][f]);
-                }
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int f = 0; f < TAIL; ++f) acc2[mf][f] = HX<F16>::mfma(w2[f], a2[mf], acc2[mf][f]);
             }
             const int c2base = g * 4 * TAIL;
             if constexpr (T16) {

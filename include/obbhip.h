@@ -43,8 +43,10 @@ int obb_ctx_destroy(obb_ctx *ctx);
 const char *obb_last_error(const obb_ctx *ctx);
 
 /* Engine knobs (no reference counterpart).  "precision": 16 = fp16 activation/weight storage (default; what
- * Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32 accumulation either way.  Applies to the next
- * obb_model_load.  "model_slot": index of the model that obb_model_load / obb_forward / obb_decode* address
+ * Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32 accumulation either way.  32 = fp32 arithmetic end to end (what
+ * the reference computes: Detect_OBB.py:79-83 calls the model with half=False): fp32 weights and activations, convolutions on the exact-f32
+ * matrix instruction (a k-ordered fmaf chain), one kernel per layer, no fusion; error bound vs an fp64 evaluation ~1e-7 * sum|a*b| per
+ * layer, i.e. the same class as any other fp32 conv.  Applies to the next obb_model_load.  "model_slot": index of the model that obb_model_load / obb_forward / obb_decode* address
  * (several models may live in one context, e.g. the 128 px and 416 px checkpoints of the dual-scale config).
  * "fuse": 1 = run the C3k2 block of the stem and the class / angle branches of the head as LDS-resident layer chains
  * (same rounding points, intermediates never reach HBM), 0 = one kernel per layer (default).  "tail": 1 = the last

@@ -8,6 +8,8 @@ otherwise **parity unpinned** (no real checkpoint or Ultralytics install is avai
 
 Precisions:
   * "fp32"          -- what the reference computes on CPU (half=False).
+  * "fp64"          -- the same fp32 weights and inputs evaluated in double precision: the yardstick that tells how far any fp32
+                       evaluation (torch's own included) sits from the exact result of the same network.
   * "f16" / "bf16"  -- same graph with the HIP path's rounding points (16-bit storage of every activation tensor and
                        of the weights, fp32 accumulate/bias/SiLU/residual) so that kernel bugs are not hidden behind
                        a loose tolerance.
@@ -231,7 +233,10 @@ class Yolo11OBB:
             r.w = (r.w / sd.view(-1, 1, 1, 1)).contiguous()
             r.b = r.b - mu / sd if not final else r.b - mu / sd
         w = half_round(r.w, self.mode) if self.bf16 else r.w
-        y = F.conv2d(x, w, r.b, stride=r.s, padding=r.k // 2, groups=r.g)
+        b = r.b
+        if self.mode == "fp64":
+            w, b = w.double(), b.double()
+        y = F.conv2d(x, w, b, stride=r.s, padding=r.k // 2, groups=r.g)
         if r.act:
             y = y / (1.0 + torch.exp(-y))  # SiLU
         if residual is not None:
@@ -293,6 +298,8 @@ class Yolo11OBB:
         if self.ch == 3:
             x = x.flip(-1)  # BGR -> RGB only for 3-channel input (Appendix A2)
         x = self._q(x.permute(0, 3, 1, 2).float() / 255.0)
+        if precision == "fp64":
+            x = x.double()
         x0 = self._apply_conv("model.0", x)
         x1 = self._apply_conv("model.1", x0)
         x2 = self._c3k2_f(2, x1)

@@ -26,6 +26,7 @@ struct obb_ctx {
     std::map<int, std::shared_ptr<obb::Model>> slots;    // parked models (obb_set_option "model_slot")
     int slot = 0;
     bool opt_f16 = true;
+    bool opt_f32 = false;  // fp32 arithmetic end to end ("precision" = 32)
     bool opt_tail = true;
     bool opt_fuse = false;  // LDS-resident layer chains (fused.hip): parity-tested, but slower than layer-by-layer on MI355X so far
     void *workspace(int slot, size_t bytes);

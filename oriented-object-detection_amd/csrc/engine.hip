@@ -17,6 +17,7 @@
 #include "c3kimg.h"
 #include "ctx.h"
 #include "dwpw.h"
+#include "f32path.h"
 #include "fused.h"
 #include "nnops.h"
 #include "stem.h"
@@ -45,7 +46,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
+enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
 
 struct Op {
     OpType type;
@@ -54,6 +55,7 @@ struct Op {
     int H = 0, W = 0;        // input spatial dims
     int Ho = 0, Wo = 0;      // output spatial dims
     ConvLaunch conv;         // OP_CONV
+    Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
     FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
@@ -64,6 +66,7 @@ struct Op {
     bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
     const bf16_t *dw_w = nullptr;  // OP_DW (device): 16-bit [9][C]
     const float *dw_b = nullptr;
+    const float *dw_w32 = nullptr;  // OP_DW in fp32 mode: fp32 [9][C]
     int act = 0;
     int N = 0, nh = 0, kd = 0, hd = 0;  // OP_ATTN
     int head_level = -1;     // >= 0: output goes to the caller's head tensor at this level
@@ -118,12 +121,14 @@ struct Model {
     bool hmerge = true;  // sibling convs on the same input run as one launch (OBB_HMERGE=0 / "tail" = 0: separate, every tap observable)
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     bf16_t *lut_dev = nullptr;
+    float *lut32_dev = nullptr;  // fp32 mode: (float)v / 255.0f
+    bool f32 = false;  // fp32 arithmetic end to end, one kernel per layer (obb_set_option "precision" = 32)
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
     bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
     bool tail = true;  // last 1x1 conv of each head branch fused behind its producer (obb_set_option "tail")
     bool bneck = true;  // fused Bottleneck stripes at the 104 / 52 levels (obb_set_option "tail" = 0 also disables it: every tap observable)
     bool upfold = true; // Upsample + Concat in front of a 1x1 conv read in place (OBB_UPFOLD=0: materialise them)
-    ~Model() { if (lut_dev) (void)hipFree(lut_dev); }
+    ~Model() { if (lut_dev) (void)hipFree(lut_dev); if (lut32_dev) (void)hipFree(lut32_dev); }
 };
 
 // ---------------------------------------------------------------------------------------------- blob parsing ("OBBW" v1)
@@ -179,8 +184,8 @@ struct Builder {
     int buf(int H, int W, int C, const std::string &name, bool f32 = false, int blk = 0) {
         Buf b;
         static const bool blocked_on = !(getenv("OBB_BLOCKED") && atoi(getenv("OBB_BLOCKED")) == 0);
-        b.H = H; b.W = W; b.C = C; b.f32 = f32; b.name = name;
-        if (blocked_on && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
+        b.H = H; b.W = W; b.C = C; b.f32 = f32 || M.f32; b.name = name;
+        if (blocked_on && !M.f32 && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
         P.bufs.push_back(b);
         return (int)P.bufs.size() - 1;
     }
@@ -269,6 +274,26 @@ struct Builder {
         op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.one_d = (r->k == 1);
+        if (M.f32) {  // fp32-arithmetic mode: one exact-f32 MFMA kernel per layer
+            if (op.vin || tail_name) { err = set_error(ctx, OBB_ERR_STATE, "layer %s: fused forms do not exist in fp32 mode", name.c_str()); return; }
+            op.type = OP_CONV32;
+            Conv32Launch &L = op.c32;
+            const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8);
+            L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act; L.in_u8 = in_u8; L.flip_bgr = (in_u8 && M.ch == 3);
+            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC;
+            L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
+            L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
+            L.wpk = upload(pack_conv32_weights(r->w, r->c2, cin, r->k, t, perm, in_u8));
+            std::vector<float> bias32(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r->c2; ++c) bias32[c] = r->b[perm ? perm[c] : c];
+            L.bias = upload(bias32);
+            L.lut = M.lut32_dev;
+            op.macs = (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+            P.macs_per_img += op.macs;
+            P.ops.push_back(op);
+            P.named[name] = out;
+            return;
+        }
         static const bool stem_on = !(getenv("OBB_STEM") && atoi(getenv("OBB_STEM")) == 0);
         if (in_u8 && stem_on && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && r->act && stem_scale_is_exact(M.f16)) {
             op.type = OP_STEM;
@@ -342,7 +367,12 @@ struct Builder {
         Op op;
         op.type = OP_DW; op.name = name; op.in = in; op.out = out; op.res = res; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
         op.act = r->act;
-        op.dw_w = upload(w);
+        if (M.f32) {
+            std::vector<float> w32((size_t)9 * C + 8, 0.f);
+            for (int c = 0; c < C; ++c)
+                for (int t = 0; t < 9; ++t) w32[(size_t)t * C + c] = r->w[(size_t)c * 9 + t];
+            op.dw_w32 = upload(w32);
+        } else op.dw_w = upload(w);
         op.dw_b = upload(b);
         P.macs_per_img += (double)H * W * C * 9;
         P.ops.push_back(op);
@@ -811,7 +841,7 @@ struct Builder {
         int cat9 = buf(H32, W32, 4 * c_, "cat9");
         conv("model.9.cv1", whole(b8), H32, W32, sub(cat9, 0, c_));
         static const bool sppf_one = !(getenv("OBB_SPPF_FUSE") && atoi(getenv("OBB_SPPF_FUSE")) == 0);
-        if (sppf_one && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
+        if (sppf_one && !M.f32 && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
             Op op; op.type = OP_SPPF; op.name = "sppf.pools"; op.in = sub(cat9, 0, c_); op.out = whole(cat9); op.H = H32; op.W = W32; op.Ho = H32; op.Wo = W32;
             P.ops.push_back(op);
         } else {
@@ -1025,6 +1055,26 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
     for (Op &op : P.ops) {
         hipError_t e = hipSuccess;
         switch (op.type) {
+            case OP_CONV32: {
+                Conv32Launch L = op.c32;
+                L.B = B;
+                if (op.in.buf == -1) {
+                    L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
+                } else L.in = tref(P, op.in, boff);
+                if (op.head_level >= 0) {
+                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
+                    if (op.one_d) L.out_hw = op.Ho * op.Wo;
+                } else L.out = tref(P, op.out, boff);
+                L.res = tref(P, op.res, boff);
+                if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
+                    const int64_t npx = (int64_t)B * op.Ho * op.Wo;
+                    L.B = 1; L.Hin = L.Hout = 1; L.Win = L.Wout = (int)npx;
+                    L.tiles_y = 1; L.tiles_x = (int)((npx + L.TW - 1) / L.TW);
+                }
+                e = launch_conv32(L, st);
+                break;
+            }
             case OP_CONV: {
                 ConvLaunch L = op.conv;
                 L.B = B;
@@ -1057,7 +1107,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_conv(L, st);
                 break;
             }
-            case OP_DW: e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
+            case OP_DW:
+                if (M.f32) { e = launch_dwconv3_f32(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w32, op.dw_b, B, op.H, op.W, op.in.C, op.act, st); break; }
+                e = launch_dwconv3(tref(P, op.in, boff), tref(P, op.out, boff), tref(P, op.res, boff), op.dw_w, op.dw_b, B, op.H, op.W, op.in.C, op.act, M.f16, st); break;
             case OP_C3KIMG: {
                 C3kImgLaunch L = op.c3kimg;
                 L.B = B; L.in = tref(P, op.in, boff); L.out = tref(P, op.out, boff);
@@ -1086,8 +1138,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 break;
             }
             case OP_SPPF: e = launch_sppf_pools(tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
-            case OP_POOL: e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
-            case OP_UP: e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
+            case OP_POOL:
+                if (M.f32) { e = launch_maxpool5_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break; }
+                e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
+            case OP_UP:
+                if (M.f32) { e = launch_upsample2_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break; }
+                e = launch_upsample2(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break;
             case OP_STEM: {
                 StemLaunch L = op.stem;
                 L.B = B; L.in = tiles; L.out = tref(P, op.out, boff);
@@ -1105,7 +1161,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_fused(L, st);
                 break;
             }
-            case OP_ATTN: e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
+            case OP_ATTN:
+                if (M.f32) { e = launch_attention_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, st); break; }
+                e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
     }
@@ -1152,6 +1210,15 @@ __global__ void k_half_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, 
     dst[i] = HX<F16>::one(blk > 0 ? src[(int64_t)(c / blk) * ps + b * bs + pix * blk + c % blk] : src[b * bs + pix * cs + c]);
 }
 
+__global__ void k_f32_slice_copy(const float *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B, float *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * npix_per_img * C) return;
+    int c = (int)(i % C) + co;
+    int64_t pix = (i / C) % npix_per_img;
+    int64_t b = i / ((int64_t)C * npix_per_img);
+    dst[i] = src[b * bs + pix * cs + c];
+}
+
 }  // namespace obb
 
 using namespace obb;
@@ -1167,11 +1234,19 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     int rc = parse_blob(ctx, *M);
     if (rc) return rc;
     M->f16 = ctx->opt_f16;
+    M->f32 = ctx->opt_f32;
     M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
     M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
     M->upfold = !(getenv("OBB_UPFOLD") && atoi(getenv("OBB_UPFOLD")) == 0);
+    if (M->f32) { M->fuse = false; M->tail = false; M->upfold = false; }  // fp32 arithmetic: one kernel per layer, fp32 NHWC buffers
     M->hmerge = M->tail && !(getenv("OBB_HMERGE") && atoi(getenv("OBB_HMERGE")) == 0);
     M->bneck = M->tail;  // both swallow intermediate activations: one switch ("tail" = 0 keeps every layer observable)
+    if (M->f32) {  // `im.float() / 255`: IEEE division, one table entry per byte value
+        std::vector<float> lut32(256);
+        for (int v = 0; v < 256; ++v) lut32[v] = (float)v / 255.0f;
+        OBB_HIP(ctx, hipMalloc((void **)&M->lut32_dev, 1024));
+        OBB_HIP(ctx, hipMemcpy(M->lut32_dev, lut32.data(), 1024, hipMemcpyHostToDevice));
+    }
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
@@ -1184,9 +1259,10 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
     OBB_REQUIRE(ctx, ctx && key, "obb_set_option: bad arguments");
     std::string k(key);
-    if (k == "precision") {  // 16 = fp16 storage (default), 1016 = bf16 storage; takes effect at the next obb_model_load
-        OBB_REQUIRE(ctx, value == 16 || value == 1016, "obb_set_option: precision must be 16 (fp16) or 1016 (bf16)");
-        ctx->opt_f16 = (value == 16);
+    if (k == "precision") {  // 16 = fp16 storage (default), 1016 = bf16 storage, 32 = fp32 arithmetic end to end; next obb_model_load
+        OBB_REQUIRE(ctx, value == 16 || value == 1016 || value == 32, "obb_set_option: precision must be 16 (fp16), 1016 (bf16) or 32 (fp32)");
+        ctx->opt_f16 = (value != 1016);
+        ctx->opt_f32 = (value == 32);
         return OBB_OK;
     }
     if (k == "fuse") {  // 1 = LDS-resident layer chains (fused.hip), 0 = one kernel per layer (default; every activation observable); next obb_model_load
@@ -1283,6 +1359,12 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
         const char *ty = "?";
         int grid_x = 0, grid_y = 0, lds = 0;
         switch (op.type) {
+            case OP_CONV32: {
+                const Conv32Launch &L = op.c32;
+                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d CK%d WC%d lds%d macs%.0f\n", op.name.c_str(), L.ks, L.stride, L.cin,
+                         L.cout, op.Ho, op.Wo, L.TH, L.TW, L.CK, L.WC, (int)conv32_lds_bytes(L), op.macs);
+                break;
+            }
             case OP_CONV: {
                 ty = "conv";
                 const ConvLaunch &L = op.conv;
@@ -1341,7 +1423,10 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
     OBB_REQUIRE(ctx, max_elems >= n, "obb_debug_activation: output too small (%lld < %lld)", (long long)max_elems, (long long)n);
     const int64_t hw = (int64_t)b.H * b.W;
     const int64_t d_bs = b.blk > 0 ? hw * b.blk : b.per_img(), d_ps = b.blk > 0 ? (int64_t)P->cap * hw * b.blk : 0;
-    if (ctx->model->f16)
+    if (b.f32)
+        hipLaunchKernelGGL(k_f32_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const float *)b.p, (int64_t)b.per_img(), b.C, sl.co, sl.C, hw,
+                           B, out);
+    else if (ctx->model->f16)
         hipLaunchKernelGGL(k_half_slice_to_f32<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, d_bs, b.C,
                            sl.co, sl.C, hw, B, out, b.blk, d_ps);
     else

@@ -191,7 +191,7 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
 
 # ---------------------------------------------------------------- S1 model
 
-PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016}
+PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016, "f32": 32, "fp32": 32}
 
 
 def select_model(slot, device=None):

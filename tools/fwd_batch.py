@@ -4,8 +4,11 @@ import make_weights
 import oriented_object_detection_amd
 from oriented_object_detection_amd import ops
 from oriented_object_detection_amd.model import YOLO
-m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416)
-for B in (8, 16, 32, 64, 128, 256, 512):
+import os
+prec = os.environ.get("OBB_PREC", "f16")
+m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416, precision=prec)
+print("precision", prec)
+for B in [int(v) for v in os.environ.get('OBB_BATCHES', '8,16,32,64,128,256,512').split(',')]:
     tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()
     for _ in range(3): ops.forward(tiles)
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "report":
     f = glob.glob(sys.argv[2] + "/*/*_kernel_trace.csv")[0]
     rows = [r for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ker = [r for r in rows if "obb::k_conv" in r["Kernel_Name"] or "k_dwconv3" in r["Kernel_Name"] or "k_maxpool5" in r["Kernel_Name"] or "k_upsample2" in r["Kernel_Name"] or "k_attention" in r["Kernel_Name"] or "k_fused_chain" in r["Kernel_Name"] or "k_stem_conv" in r["Kernel_Name"] or "k_sppf_pools" in r["Kernel_Name"] or "k_bneck_stripe" in r["Kernel_Name"] or "k_c3k_image" in r["Kernel_Name"] or "k_dwpw_stripe" in r["Kernel_Name"]]
+    ker = [r for r in rows if "obb::k_conv" in r["Kernel_Name"] or "k_dwconv3" in r["Kernel_Name"] or "k_maxpool5" in r["Kernel_Name"] or "k_upsample2" in r["Kernel_Name"] or "k_attention" in r["Kernel_Name"] or "k_fused_chain" in r["Kernel_Name"] or "k_stem_conv" in r["Kernel_Name"] or "k_sppf_pools" in r["Kernel_Name"] or "k_bneck_stripe" in r["Kernel_Name"] or "k_c3k_image" in r["Kernel_Name"] or "k_dwpw_stripe" in r["Kernel_Name"] or "_f32" in r["Kernel_Name"]]
     nf = len(ker) // len(ops)
     ker = ker[-len(ops):]  # last forward
     tot = 0
@@ -31,7 +31,7 @@ else:
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/layers"
     os.makedirs(out, exist_ok=True)
-    m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416)
+    m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416, precision=os.environ.get("OBB_PREC", "f16"))
     open(out + "/plan.txt", "w").write("\n".join(ops.debug_plan(416, 416)))
     open(out + "/B.txt", "w").write(str(B))
     tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()

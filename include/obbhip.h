@@ -42,16 +42,25 @@ int obb_ctx_destroy(obb_ctx *ctx);
 /* Last error text of this context (or of the calling thread when ctx == NULL). */
 const char *obb_last_error(const obb_ctx *ctx);
 
-/* Engine knobs (no reference counterpart).  "precision": 16 = fp16 activation/weight storage (default; what
- * Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32 accumulation either way.  32 = fp32 arithmetic end to end (what
- * the reference computes: Detect_OBB.py:79-83 calls the model with half=False): fp32 weights and activations, convolutions on the exact-f32
- * matrix instruction (a k-ordered fmaf chain), one kernel per layer, no fusion; error bound vs an fp64 evaluation ~1e-7 * sum|a*b| per
- * layer, i.e. the same class as any other fp32 conv.  Applies to the next obb_model_load.  "model_slot": index of the model that obb_model_load / obb_forward / obb_decode* address
- * (several models may live in one context, e.g. the 128 px and 416 px checkpoints of the dual-scale config).
- * "fuse": 1 = run the C3k2 block of the stem and the class / angle branches of the head as LDS-resident layer chains
- * (same rounding points, intermediates never reach HBM), 0 = one kernel per layer (default).  "tail": 1 = the last
- * 1x1 conv of each head branch runs fused behind its producer (default), 0 = separate launch.  Both apply to the next
- * obb_model_load. */
+/* Engine knobs (no reference counterpart).
+ *   "precision"   16 = fp16 activation/weight storage (default; what Ultralytics' half=True inference uses), 1016 = bf16 storage; fp32
+ *                 accumulation either way.  32 = fp32 arithmetic end to end (what the reference computes: Detect_OBB.py:79-83 calls the
+ *                 model with half=False): fp32 weights and activations, convolutions on the exact-f32 matrix instruction (a k-ordered
+ *                 fmaf chain), one kernel per layer, no fusion; error vs a double-precision evaluation of the same weights ~1e-5 on a
+ *                 head logit, the same as torch's own fp32 forward (tests/test_gpu_fp32.py).  Applies to the next obb_model_load.
+ *   "model_slot"  index (0..63) of the model that obb_model_load / obb_forward / obb_decode* address (several models may live in one
+ *                 context, e.g. the 128 px and 416 px checkpoints of the dual-scale config).
+ *   fused forms, 1 = on (default), 0 = the separate launches they replace; each applies to the next obb_model_load and exists so that
+ *   parity tests can compare both forms on identical inputs:
+ *     "tail"      last 1x1 conv of each head branch behind its producer; 0 also turns every other intermediate-swallowing fusion off
+ *                 (bneck, hmerge, c3kimg, dwpw, tail16): every layer's output is then observable through obb_debug_activation
+ *     "tail16"    cv1 of the C3k2 blocks 2 / 4 inside the preceding stride-2 conv      "bneck"     Bottleneck row stripes (104 / 52 levels)
+ *     "bneck_cv2" closing 1x1 of those C3k2 blocks behind the Bottleneck               "c3kimg"    inner C3k of the stride-32 level per image
+ *     "dwpw"      depthwise 3x3 -> 1x1 stripes of the class branch                     "upfold"    Upsample + Concat read in place by the 1x1
+ *     "stem"      model.0 as row stripes on the uint8 tile                             "hmerge"    sibling convs on one input as one launch
+ *     "sppf_fuse" the three SPPF pools in one launch                                   "attn_mfma" C2PSA attention on the matrix cores
+ *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 1..3
+ *   concurrent sub-batch chains (default 2), "microbatch" tiles per round (default and maximum 1024). */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */
@@ -86,7 +95,8 @@ int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep,
 int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n,
                          double thr, int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
 /* Batched form for the per-tile call at Detect_OBB.py:264: nseg independent segments, segment k owning rows
- * [seg_off[k], seg_off[k+1]) (device int32[nseg+1]); order holds GLOBAL row indices per sorted position. */
+ * [seg_off[k], seg_off[k+1]) (device int32[nseg+1]); order holds GLOBAL row indices per sorted position.  Segments of up to 512 rows run
+ * in one launch; longer ones are detected on the host and taken through the dense path of obb_merge_detections (synchronises then). */
 int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf,
                        const int32_t *seg_off, int32_t nseg, int64_t n, double thr, int32_t *order, uint8_t *keep,
                        obb_stream_t s);
@@ -124,6 +134,8 @@ int obb_letterbox(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int3
 /* Weight blob ("OBBW" format, produced by the Python side from BN-folded conv weights) for a
  * YOLO11-OBB graph (ultralytics==8.3.196 yolo11-obb.yaml).  Host pointer.  (synchronises) */
 int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes);
+/* Frees the model of `slot` (weights, activation slabs, captured graphs); the slot can be loaded again.  (synchronises) */
+int obb_model_unload(obb_ctx *ctx, int32_t slot);
 /* nc, input channels, number of anchors A for an (h, w) input, number of weight records. */
 int obb_model_info(const obb_ctx *ctx, int32_t h, int32_t w, int32_t *nc, int32_t *ch, int32_t *anchors, int32_t *nconv);
 /* OBBModel forward on B letterboxed inputs: tiles uint8[B*h*w*ch] (NHWC; BGR for ch==3 exactly as the reference

@@ -34,6 +34,7 @@ SIGNATURES = {
     "obb_letterbox": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V,
                       C.c_int32, C.c_int32, _V],
     "obb_model_load": [_V, _V, C.c_size_t],
+    "obb_model_unload": [_V, C.c_int32],
     "obb_model_info": [_V, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip],
     "obb_forward": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V],
     "obb_debug_plan": [_V, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, c_lp],

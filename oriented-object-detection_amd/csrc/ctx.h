@@ -13,7 +13,15 @@
 #include "../../include/obbhip.h"
 
 namespace obb {
-struct Model;  // engine.h
+struct Model;  // engine.hip
+// obb_set_option switches of the forward engine.  Every fused form keeps a switch that restores its separate launches: the A/B parity
+// tests compare the two on identical inputs.  graph / fwd_split / microbatch steer how a forward is issued (their defaults may be
+// preset from the environment for profiling runs: OBB_GRAPH, OBB_FWD_SPLIT, OBB_MICROBATCH -- read once per context).
+struct EngineOpts {
+    bool tail = true, tail16 = true, bneck = true, bneck_cv2 = true, c3kimg = true, dwpw = true, upfold = true, stem = true, hmerge = true,
+         sppf_fuse = true, attn_mfma = true, graph = true;
+    int fwd_split = 2, microbatch = 1024;
+};
 }
 
 struct obb_ctx {
@@ -27,8 +35,7 @@ struct obb_ctx {
     int slot = 0;
     bool opt_f16 = true;
     bool opt_f32 = false;  // fp32 arithmetic end to end ("precision" = 32)
-    bool opt_tail = true;
-    bool opt_fuse = false;  // LDS-resident layer chains (fused.hip): parity-tested, but slower than layer-by-layer on MI355X so far
+    obb::EngineOpts opt;   // obb_set_option switches
     void *workspace(int slot, size_t bytes);
     ~obb_ctx();
 };

@@ -1,6 +1,9 @@
 // Context lifetime + error plumbing of libobbhip.so (C-ABI in include/obbhip.h).
 #include "ctx.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace obb {
 thread_local std::string g_tls_error;
 
@@ -54,6 +57,9 @@ int obb_ctx_create(int device, obb_ctx **out) {
                               device, prop.gcnArchName);
     obb_ctx *c = new obb_ctx();
     c->device = device;
+    if (const char *v = getenv("OBB_GRAPH")) c->opt.graph = atoi(v) != 0;  // profiling presets (per-layer kernel traces want eager, one-chain runs)
+    if (const char *v = getenv("OBB_FWD_SPLIT")) c->opt.fwd_split = std::max(1, std::min(3, atoi(v)));
+    if (const char *v = getenv("OBB_MICROBATCH")) c->opt.microbatch = std::max(1, std::min(1024, atoi(v)));
     *out = c;
     return OBB_OK;
 }

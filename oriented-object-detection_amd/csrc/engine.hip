@@ -18,7 +18,6 @@
 #include "ctx.h"
 #include "dwpw.h"
 #include "f32path.h"
-#include "fused.h"
 #include "nnops.h"
 #include "stem.h"
 
@@ -46,7 +45,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_FUSED, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
+enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
 
 struct Op {
     OpType type;
@@ -56,12 +55,11 @@ struct Op {
     int Ho = 0, Wo = 0;      // output spatial dims
     ConvLaunch conv;         // OP_CONV
     Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
-    FusedLaunch fused;       // OP_FUSED (LDS-resident layer chain)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
     C3kImgLaunch c3kimg;     // OP_C3KIMG (inner C3k of the stride-32 level, one persistent workgroup per image)
     DwPwLaunch dwpw;         // OP_DWPW (depthwise 3x3 -> 1x1 [-> plain 1x1 to the head] over row stripes)
-    double macs = 0;         // OP_FUSED: MACs of all fused layers
+    double macs = 0;         // MACs of all layers of a multi-layer op
     bool one_d = false;
     bool vin = false;        // OP_CONV: the input is a virtual upsample-concat buffer
     const bf16_t *dw_w = nullptr;  // OP_DW (device): 16-bit [9][C]
@@ -93,10 +91,12 @@ struct Plan {
     typedef std::tuple<int, const void *, void *> GraphKey;
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> seen;
+    std::vector<GraphKey> graph_order;  // insertion order of `graphs` (eviction)
     void drop_graphs() {
         for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
         graphs.clear();
         seen.clear();
+        graph_order.clear();
     }
     ~Plan() {
         drop_graphs();
@@ -118,16 +118,17 @@ struct Model {
     std::map<std::string, ConvRecord> recs;
     int nrec_blob = 0;  // records of the weight blob itself (synthesised merged records are added to `recs` while plans are built)
     std::map<std::string, std::pair<std::vector<float>, std::vector<float>>> merged;  // weights / bias of synthesised (cout-concatenated) records
-    bool hmerge = true;  // sibling convs on the same input run as one launch (OBB_HMERGE=0 / "tail" = 0: separate, every tap observable)
+    bool hmerge = true;  // sibling convs on the same input run as one launch ("hmerge" / "tail" = 0: separate, every tap observable)
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     bf16_t *lut_dev = nullptr;
     float *lut32_dev = nullptr;  // fp32 mode: (float)v / 255.0f
     bool f32 = false;  // fp32 arithmetic end to end, one kernel per layer (obb_set_option "precision" = 32)
     bool f16 = true;  // storage precision of activations/weights (obb_set_option "precision")
-    bool fuse = false; // LDS-resident layer chains (obb_set_option "fuse")
-    bool tail = true;  // last 1x1 conv of each head branch fused behind its producer (obb_set_option "tail")
-    bool bneck = true;  // fused Bottleneck stripes at the 104 / 52 levels (obb_set_option "tail" = 0 also disables it: every tap observable)
-    bool upfold = true; // Upsample + Concat in front of a 1x1 conv read in place (OBB_UPFOLD=0: materialise them)
+    // fused forms, each with its obb_set_option switch (EngineOpts in ctx.h); "tail" = 0 turns every intermediate-swallowing one off
+    bool tail = true;    // last 1x1 conv of each head branch fused behind its producer
+    bool bneck = true;   // fused Bottleneck stripes at the 104 / 52 levels
+    bool upfold = true;  // Upsample + Concat in front of a 1x1 conv read in place
+    EngineOpts o;        // the remaining switches as they stood at obb_model_load
     ~Model() { if (lut_dev) (void)hipFree(lut_dev); if (lut32_dev) (void)hipFree(lut32_dev); }
 };
 
@@ -149,17 +150,18 @@ static int parse_blob(obb_ctx *ctx, Model &M) {
     M.nc = H.nc; M.ch = H.ch; M.width = H.width; M.depth = H.depth; M.max_ch = H.max_ch;
     M.scale = std::string(H.scale, strnlen(H.scale, 8));
     size_t tbl = sizeof(BlobHeader);
-    if (tbl + (size_t)H.nrec * sizeof(BlobRec) > n) return set_error(ctx, OBB_ERR_FORMAT, "record table truncated");
+    if ((size_t)H.nrec > (n - tbl) / sizeof(BlobRec)) return set_error(ctx, OBB_ERR_FORMAT, "record table truncated");
     for (uint32_t i = 0; i < H.nrec; ++i) {
         BlobRec R;
         memcpy(&R, M.blob.data() + tbl + i * sizeof(BlobRec), sizeof R);
         ConvRecord c;
         c.name = std::string(R.name, strnlen(R.name, 64));
         c.c1 = R.c1; c.c2 = R.c2; c.k = R.k; c.s = R.s; c.g = R.g; c.act = R.act;
-        if (c.c1 <= 0 || c.c2 <= 0 || (c.k != 1 && c.k != 3) || c.g <= 0 || c.c1 % c.g)
+        if (c.c1 <= 0 || c.c2 <= 0 || c.c1 > 8192 || c.c2 > 8192 || (c.k != 1 && c.k != 3) || (c.s != 1 && c.s != 2) || c.g <= 0 || c.c1 % c.g)
             return set_error(ctx, OBB_ERR_FORMAT, "record %s: unsupported conv shape", c.name.c_str());
-        size_t wn = (size_t)c.c2 * (c.c1 / c.g) * c.k * c.k * 4, bn = (size_t)c.c2 * 4;
-        if (R.w_off % 4 || R.b_off % 4 || R.w_off + wn > n || R.b_off + bn > n)
+        const size_t wn = (size_t)c.c2 * (c.c1 / c.g) * c.k * c.k * 4, bn = (size_t)c.c2 * 4;  // <= 8192 * 8192 * 36: no overflow
+        // subtraction forms: an offset near 2^64 must not wrap past the end check
+        if (R.w_off % 4 || R.b_off % 4 || R.w_off > n || wn > n - R.w_off || R.b_off > n || bn > n - R.b_off)
             return set_error(ctx, OBB_ERR_FORMAT, "record %s: data out of range", c.name.c_str());
         c.w = reinterpret_cast<const float *>(M.blob.data() + R.w_off);
         c.b = reinterpret_cast<const float *>(M.blob.data() + R.b_off);
@@ -183,9 +185,8 @@ struct Builder {
 
     int buf(int H, int W, int C, const std::string &name, bool f32 = false, int blk = 0) {
         Buf b;
-        static const bool blocked_on = !(getenv("OBB_BLOCKED") && atoi(getenv("OBB_BLOCKED")) == 0);
         b.H = H; b.W = W; b.C = C; b.f32 = f32 || M.f32; b.name = name;
-        if (blocked_on && !M.f32 && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
+        if (!M.f32 && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
         P.bufs.push_back(b);
         return (int)P.bufs.size() - 1;
     }
@@ -239,8 +240,7 @@ struct Builder {
     // true if the 1x1 conv `tail_name` (with activation, 16-bit output) can run inside the launch of its only producer `name`
     // (a 3x3 conv holding all of its output channels in one workgroup): stride-2 backbone conv -> cv1 of the next C3k2 block
     bool tail16_ok(const std::string &name, const std::string &tail_name, int Hin, int Win) {
-        const bool on = !(getenv("OBB_TAIL16") && atoi(getenv("OBB_TAIL16")) == 0);
-        if (!M.tail || !on) return false;
+        if (!M.tail || !M.o.tail16) return false;
         const ConvRecord *r = rec(name), *r2 = rec(tail_name);
         if (!r || !r2 || err) return false;
         if (r->g != 1 || r2->g != 1 || r->k != 3 || r2->k != 1 || r2->s != 1 || !r2->act || !r->act || r2->c1 != r->c2) return false;
@@ -294,8 +294,7 @@ struct Builder {
             P.named[name] = out;
             return;
         }
-        static const bool stem_on = !(getenv("OBB_STEM") && atoi(getenv("OBB_STEM")) == 0);
-        if (in_u8 && stem_on && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && r->act && stem_scale_is_exact(M.f16)) {
+        if (in_u8 && M.o.stem && !perm && head_level < 0 && !res.C && stem_supported(cin, r->c2, r->k, r->s, Hin, Win) && r->act && stem_scale_is_exact(M.f16)) {
             op.type = OP_STEM;
             StemLaunch &S = op.stem;
             S.Hin = Hin; S.Win = Win; S.cin = cin; S.cout = r->c2; S.act = r->act; S.f16 = M.f16;
@@ -382,7 +381,7 @@ struct Builder {
     // DWConv 3x3 `dwname` -> Conv 1x1 `pwname` [-> plain 1x1 `tailname` into the head tensor] as one stripe kernel (dwpw.hip).
     // Returns false (nothing emitted) if the shapes have no kernel.
     bool dwpw(const std::string &dwname, const std::string &pwname, Slice in, int H, int W, Slice out, const char *tailname = nullptr, int head_level = -1) {
-        const bool on = M.tail && !(getenv("OBB_DWPW") && atoi(getenv("OBB_DWPW")) == 0);
+        const bool on = M.tail && M.o.dwpw;
         const ConvRecord *rd = rec(dwname), *rp = rec(pwname), *rt = tailname ? rec(tailname) : nullptr;
         if (!on || !rd || !rp || (tailname && !rt) || err) return false;
         if (in.buf < 0 || P.bufs[in.buf].blk || P.bufs[in.buf].virt || rd->g != rd->c1 || rd->c1 != rd->c2 || rd->k != 3 || rd->s != 1 || rd->c1 != in.C || !rd->act ||
@@ -460,8 +459,7 @@ struct Builder {
     bool bottleneck(const std::string &name, Slice in, int H, int W, Slice out, double e, const char *cv2name = nullptr, Slice y0 = Slice(),
                     Slice cv2out = Slice()) {
         int c_ = (int)(out.C * e);
-        const bool bneck_on = !(getenv("OBB_BNECK") && atoi(getenv("OBB_BNECK")) == 0);
-        if (bneck_on && M.bneck && in.buf >= 0 && in.buf == out.buf && P.bufs[in.buf].blk == in.C && in.C == out.C && c_ * 2 == in.C &&
+        if (M.bneck && in.buf >= 0 && in.buf == out.buf && P.bufs[in.buf].blk == in.C && in.C == out.C && c_ * 2 == in.C &&
             bneck_supported(in.C, H, W)) {
             const ConvRecord *r1 = rec(name + ".cv1"), *r2 = rec(name + ".cv2");
             if (!r1 || !r2 || err) return false;
@@ -481,8 +479,7 @@ struct Builder {
                 op.macs = (double)H * W * 9.0 * in.C * c_ * 2;
                 bool fused_cv2 = false;
                 const ConvRecord *rc = cv2name ? rec(cv2name) : nullptr;
-                const bool cv2_on = !(getenv("OBB_BNECK_CV2") && atoi(getenv("OBB_BNECK_CV2")) == 0);
-                if (rc && cv2_on && rc->k == 1 && rc->s == 1 && rc->g == 1 && rc->act && rc->c1 == 3 * in.C && rc->c2 == cv2out.C && cv2out.buf >= 0 &&
+                if (rc && M.o.bneck_cv2 && rc->k == 1 && rc->s == 1 && rc->g == 1 && rc->act && rc->c1 == 3 * in.C && rc->c2 == cv2out.C && cv2out.buf >= 0 &&
                     !P.bufs[cv2out.buf].virt && y0.buf == in.buf && y0.C == in.C && y0.co + in.C == in.co && in.co + in.C == out.co &&
                     bneck_cv2_supported(in.C, rc->c2)) {
                     ConvTiling tc{1, 1, 1, rc->c2 / 16, in.C == 32 ? 96 : 32};
@@ -512,7 +509,7 @@ struct Builder {
 
     void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
         int c_ = out.C / 2;
-        const bool img_on = M.hmerge && !(getenv("OBB_C3KIMG") && atoi(getenv("OBB_C3KIMG")) == 0);
+        const bool img_on = M.hmerge && M.o.c3kimg;
         if (img_on && in.buf >= 0 && out.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !P.bufs[out.buf].blk &&
             c3kimg_supported(H, W, in.C, c_, out.C, n)) {
             // the whole block in one launch: weight stream = the six layers' MFMA fragments back to back
@@ -597,8 +594,6 @@ struct Builder {
             c3k2_rest(name, cat, c, H, W, out, n, use_c3k);
             return;
         }
-        if (M.fuse && n == 1 && !use_c3k && in.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !(out.buf >= 0 && P.bufs[out.buf].blk) && fused_c3k2(name, in, H, W, out, e)) return;
-        if (err) return;
         // [y0 | y1 | y2 ...]: the bottleneck reads / writes single members of this concat -> one dense block per member
         int cat = buf(H, W, (2 + n) * c, name + ".cat", false, use_c3k ? 0 : c);
         conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
@@ -615,187 +610,6 @@ struct Builder {
         conv(name + ".cv2", whole(cat), H, W, out);
     }
 
-
-    // ------------------------------------------------------------------ LDS-resident chains (fused.h)
-    struct Region { int off = 0, pst = 0, w = 0; };
-    struct Chain {
-        FusedLaunch L;
-        std::vector<bf16_t> w;  // all steps' weights (16-bit), in step order
-        int lds = 0;
-        double macs = 0;
-        int alloc(int64_t bytes) { int o = lds; lds += (int)((bytes + 15) / 16 * 16); return o; }
-    };
-    static int pst_for(int C) { return C == 8 ? 16 : C * 2 + 16; }  // +16 B spreads consecutive pixels over the LDS banks
-    static int pick_tile(int n) {  // tile edge with the least padding; 13 divides every level of a 416-px tile
-        int best = 13;
-        double bw = 1e9;
-        for (int t : {13, 12, 8}) {
-            double waste = (double)((n + t - 1) / t * t) / n;
-            if (waste < bw - 1e-9) { bw = waste; best = t; }
-        }
-        return best;
-    }
-    static int ilog2i(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
-
-    FusedStep *chain_conv(Chain &C, const std::string &name, int cin, int cout, int ks) {
-        const ConvRecord *r = rec(name);
-        if (!r || err) return nullptr;
-        if (r->g != 1 || r->c1 != cin || r->c2 != cout || r->k != ks || r->s != 1) {
-            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: shape does not match the fused graph", name.c_str());
-            return nullptr;
-        }
-        FusedStep &S = C.L.steps[C.L.nsteps++];
-        S = FusedStep();
-        S.type = FS_CONV; S.cin = cin; S.cout = cout; S.ks = ks; S.sh = ilog2i(cin / 8); S.act = r->act;
-        S.NF = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
-        S.ncb = (cout + 16 * S.NF - 1) / (16 * S.NF);
-        ConvTiling t{1, 1, 1, S.NF, cin};  // a single channel stage: k = (tap, cin) over ALL input channels
-        S.kst = conv_ksteps(ks, cin);
-        std::vector<bf16_t> pk = pack_conv_weights(r->w, cout, cin, ks, t, nullptr, 0, M.f16);
-        S.w_off = (int)(C.w.size() * 2);  // relative to the weight block; rebased onto LDS when the chain is closed
-        C.w.insert(C.w.end(), pk.begin(), pk.end());
-        std::vector<float> bias((size_t)S.ncb * 16 * S.NF + 64, 0.f);
-        for (int c = 0; c < cout; ++c) bias[c] = r->b[c];
-        S.bias = upload(bias);
-        return &S;
-    }
-    FusedStep *chain_dw(Chain &C, const std::string &name, int ch) {
-        const ConvRecord *r = rec(name);
-        if (!r || err) return nullptr;
-        if (r->g != r->c1 || r->c1 != r->c2 || r->k != 3 || r->s != 1 || r->c1 != ch) {
-            err = set_error(ctx, OBB_ERR_FORMAT, "record %s: not a depthwise 3x3 matching the fused graph", name.c_str());
-            return nullptr;
-        }
-        FusedStep &S = C.L.steps[C.L.nsteps++];
-        S = FusedStep();
-        S.type = FS_DW; S.cin = ch; S.cout = ch; S.ks = 3; S.sh = ilog2i(ch / 8); S.act = r->act;
-        S.w_off = (int)(C.w.size() * 2);
-        for (int t = 0; t < 9; ++t)
-            for (int c = 0; c < ch; ++c) C.w.push_back(host_to_half(r->w[(size_t)c * 9 + t], M.f16));
-        std::vector<float> bias((size_t)ch + 64, 0.f);
-        for (int c = 0; c < ch; ++c) bias[c] = r->b[c];
-        S.bias = upload(bias);
-        return &S;
-    }
-    static void step_io(FusedStep *S, int oh, int ow, int halo, const Region &in, int in_y0, int in_x0, int in_c0, const Region *out, int out_y0,
-                        int out_x0, int out_c0) {
-        S->oh = oh; S->ow = ow; S->halo = halo; S->inv_ow = 1.0f / (float)ow;
-        S->in_off = in.off; S->in_pst = in.pst; S->in_w = in.w; S->in_y0 = in_y0; S->in_x0 = in_x0; S->in_cb = in_c0 * 2;
-        if (out) { S->out_off = out->off; S->out_pst = out->pst; S->out_w = out->w; S->out_y0 = out_y0; S->out_x0 = out_x0; S->out_cb = out_c0 * 2; }
-    }
-    // closes a chain: weights behind the activation regions, LDS budget check, op emission.  Returns false if it does not fit.
-    bool chain_emit(Chain &C, const std::string &name, Slice in, Slice out, int H, int W, int head_level, size_t ops_mark) {
-        while (C.w.size() % 8) C.w.push_back(0);
-        C.L.w_lds_off = C.alloc(0);
-        C.L.w_bytes = (int)(C.w.size() * 2);
-        C.lds += C.L.w_bytes;
-        if (err || C.lds > 160 * 1024) return false;
-        for (int i = 0; i < C.L.nsteps; ++i) C.L.steps[i].w_off += C.L.w_lds_off;
-        C.L.lds_bytes = C.lds;
-        C.L.wts = upload(C.w);
-        C.L.H = H; C.L.W = W; C.L.f16 = M.f16;
-        (void)ops_mark;
-        Op op;
-        op.type = OP_FUSED; op.name = name; op.in = in; op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
-        op.head_level = head_level;
-        op.fused = C.L;
-        op.macs = C.macs;
-        P.macs_per_img += C.macs;
-        P.ops.push_back(op);
-        if (out.buf >= 0) P.named[name] = out;
-        return !err;
-    }
-
-    // C3k2 with one plain Bottleneck (c3k = False, n = 1): cv1 -> m.0.cv1 -> m.0.cv2 (+shortcut) -> cv2 over [y0 | y1 | y2], all in LDS
-    bool fused_c3k2(const std::string &name, Slice in, int H, int W, Slice out, double e) {
-        const int c1 = in.C, c2 = out.C, c = (int)(c2 * e), chid = c / 2;
-        if (c1 % 8 || (c1 & (c1 - 1)) || c % 8 || (c & (c - 1)) || chid % 8 || c2 % 8) return false;
-        Chain C;
-        const int TH = pick_tile(H), TW = pick_tile(W);
-        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
-        Region X, CAT, T, OUT;
-        X.pst = pst_for(c1); X.w = w2;
-        OUT.pst = pst_for(c2); OUT.w = TW;
-        X.off = OUT.off = C.alloc(std::max((int64_t)h2 * w2 * X.pst, (int64_t)TH * TW * OUT.pst));  // the input block is dead once cv1 ran
-        CAT.pst = pst_for(3 * c); CAT.w = w2; CAT.off = C.alloc((int64_t)h2 * w2 * CAT.pst);
-        T.pst = pst_for(chid); T.w = w1; T.off = C.alloc((int64_t)h1 * w1 * T.pst);
-        int64_t w_est = (int64_t)(conv_ksteps(1, c1) * ((2 * c + 15) / 16) + conv_ksteps(3, c) * ((chid + 15) / 16) + conv_ksteps(3, chid) * ((c + 15) / 16) +
-                                  conv_ksteps(1, 3 * c) * ((c2 + 15) / 16)) * 1024;
-        if (C.lds + w_est > 80 * 1024 || (int64_t)h2 * w2 * (c1 / 8) > 6 * kFusedThreads) return false;  // worth it only with two groups per CU
-        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = c1; C.L.in_off = X.off; C.L.in_pst = X.pst;
-        FusedStep *s;
-        if (!(s = chain_conv(C, name + ".cv1", c1, 2 * c, 1))) return false;
-        step_io(s, h2, w2, 2, X, 0, 0, 0, &CAT, 0, 0, 0); s->mask = 1;
-        if (!(s = chain_conv(C, name + ".m.0.cv1", c, chid, 3))) return false;
-        step_io(s, h1, w1, 1, CAT, 0, 0, c, &T, 0, 0, 0); s->mask = 1;
-        if (!(s = chain_conv(C, name + ".m.0.cv2", chid, c, 3))) return false;
-        step_io(s, TH, TW, 0, T, 0, 0, 0, &CAT, 2, 2, 2 * c);
-        s->res_off = CAT.off; s->res_pst = CAT.pst; s->res_w = CAT.w; s->res_y0 = 2; s->res_x0 = 2; s->res_cb = c * 2;  // shortcut: + y1
-        if (!(s = chain_conv(C, name + ".cv2", 3 * c, c2, 1))) return false;
-        step_io(s, TH, TW, 0, CAT, 2, 2, 0, &OUT, 0, 0, 0);
-        FusedStep &st = C.L.steps[C.L.nsteps++];
-        st = FusedStep();
-        st.type = FS_STORE; st.cin = c2;
-        step_io(&st, TH, TW, 0, OUT, 0, 0, 0, nullptr, 0, 0, 0);
-        C.macs = (double)H * W * ((double)c1 * 2 * c + 9.0 * c * chid + 9.0 * chid * c + 3.0 * c * c2);
-        return chain_emit(C, name + ".cv2", in, out, H, W, -1, 0);
-    }
-
-    // class branch of the OBB head at one level: DWConv -> 1x1 -> DWConv -> 1x1 -> 1x1 (logits, fp32 rows of the head tensor)
-    bool fused_head_cls(const std::string &p, Slice feat, int H, int W, int c3, int level) {
-        const int cf = feat.C;
-        if (cf % 8 || (cf & (cf - 1)) || c3 % 8 || (c3 & (c3 - 1))) return false;
-        Chain C;
-        const int TH = pick_tile(H), TW = pick_tile(W);
-        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
-        Region X, D1, E1, D2, E2;
-        X.pst = pst_for(cf); X.w = w2; D1.pst = pst_for(cf); D1.w = w1; E1.pst = pst_for(c3); E1.w = w1;
-        D2.pst = pst_for(c3); D2.w = TW; E2.pst = pst_for(c3); E2.w = TW;
-        int a = C.alloc(std::max({(int64_t)h2 * w2 * X.pst, (int64_t)h1 * w1 * E1.pst, (int64_t)TH * TW * E2.pst}));
-        int b = C.alloc(std::max((int64_t)h1 * w1 * D1.pst, (int64_t)TH * TW * D2.pst));
-        X.off = E1.off = E2.off = a; D1.off = D2.off = b;
-        int64_t w_est = (int64_t)9 * cf * 2 + 9 * c3 * 2 + (int64_t)(conv_ksteps(1, cf) + conv_ksteps(1, c3)) * ((c3 + 15) / 16) * 1024 + conv_ksteps(1, c3) * 1024;
-        if (C.lds + w_est > 160 * 1024 || (int64_t)h2 * w2 * (cf / 8) > 6 * kFusedThreads) return false;
-        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = cf; C.L.in_off = X.off; C.L.in_pst = X.pst;
-        FusedStep *s;
-        if (!(s = chain_dw(C, p + ".0.0", cf))) return false;
-        step_io(s, h1, w1, 1, X, 0, 0, 0, &D1, 0, 0, 0);
-        if (!(s = chain_conv(C, p + ".0.1", cf, c3, 1))) return false;
-        step_io(s, h1, w1, 1, D1, 0, 0, 0, &E1, 0, 0, 0); s->mask = 1;
-        if (!(s = chain_dw(C, p + ".1.0", c3))) return false;
-        step_io(s, TH, TW, 0, E1, 0, 0, 0, &D2, 0, 0, 0);
-        if (!(s = chain_conv(C, p + ".1.1", c3, c3, 1))) return false;
-        step_io(s, TH, TW, 0, D2, 0, 0, 0, &E2, 0, 0, 0);
-        if (!(s = chain_conv(C, p + ".2", c3, M.nc, 1))) return false;
-        step_io(s, TH, TW, 0, E2, 0, 0, 0, nullptr, 0, 0, 0); s->to_global = 1;
-        C.macs = (double)H * W * (9.0 * cf + (double)cf * c3 + 9.0 * c3 + (double)c3 * c3 + (double)c3 * M.nc);
-        return chain_emit(C, p, feat, Slice{-2, 4 * kRegMax, M.nc}, H, W, level, 0);
-    }
-
-    // angle branch of the OBB head at one level: 3x3 -> 3x3 -> 1x1 (one logit per anchor, fp32)
-    bool fused_head_angle(const std::string &p, Slice feat, int H, int W, int c4, int level) {
-        const int cf = feat.C;
-        if (cf % 8 || (cf & (cf - 1)) || c4 % 8 || (c4 & (c4 - 1))) return false;
-        Chain C;
-        const int TH = pick_tile(H), TW = pick_tile(W);
-        const int h2 = TH + 4, w2 = TW + 4, h1 = TH + 2, w1 = TW + 2;
-        Region X, U1, U2;
-        X.pst = pst_for(cf); X.w = w2; U1.pst = pst_for(c4); U1.w = w1; U2.pst = pst_for(c4); U2.w = TW;
-        X.off = U2.off = C.alloc(std::max((int64_t)h2 * w2 * X.pst, (int64_t)TH * TW * U2.pst));  // the input block is dead once the first 3x3 ran
-        U1.off = C.alloc((int64_t)h1 * w1 * U1.pst);
-        int64_t w_est = (int64_t)(conv_ksteps(3, cf) + conv_ksteps(3, c4) + conv_ksteps(1, c4)) * ((c4 + 15) / 16) * 1024;
-        if (C.lds + w_est > 80 * 1024 || (int64_t)h2 * w2 * (cf / 8) > 6 * kFusedThreads) return false;
-        C.L.TH = TH; C.L.TW = TW; C.L.in_halo = 2; C.L.in_C = cf; C.L.in_off = X.off; C.L.in_pst = X.pst;
-        FusedStep *s;
-        if (!(s = chain_conv(C, p + ".0", cf, c4, 3))) return false;
-        step_io(s, h1, w1, 1, X, 0, 0, 0, &U1, 0, 0, 0); s->mask = 1;
-        if (!(s = chain_conv(C, p + ".1", c4, c4, 3))) return false;
-        step_io(s, TH, TW, 0, U1, 0, 0, 0, &U2, 0, 0, 0);
-        if (!(s = chain_conv(C, p + ".2", c4, 1, 1))) return false;
-        step_io(s, TH, TW, 0, U2, 0, 0, 0, nullptr, 0, 0, 0); s->to_global = 1;
-        C.macs = (double)H * W * (9.0 * cf * c4 + 9.0 * c4 * c4 + (double)c4);
-        return chain_emit(C, p, feat, Slice{-2, 4 * kRegMax + M.nc, 1}, H, W, level, 0);
-    }
 
     int build() {
         const int h = P.h, w = P.w;
@@ -840,8 +654,7 @@ struct Builder {
         int c_ = c1024 / 2;
         int cat9 = buf(H32, W32, 4 * c_, "cat9");
         conv("model.9.cv1", whole(b8), H32, W32, sub(cat9, 0, c_));
-        static const bool sppf_one = !(getenv("OBB_SPPF_FUSE") && atoi(getenv("OBB_SPPF_FUSE")) == 0);
-        if (sppf_one && !M.f32 && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
+        if (M.o.sppf_fuse && !M.f32 && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
             Op op; op.type = OP_SPPF; op.name = "sppf.pools"; op.in = sub(cat9, 0, c_); op.out = whole(cat9); op.H = H32; op.W = W32; op.Ho = H32; op.Wo = W32;
             P.ops.push_back(op);
         } else {
@@ -942,8 +755,6 @@ struct Builder {
         for (int i = 0; i < 3; ++i) {
             size_t first_op = P.ops.size();
             std::string p = "model.23.cv3." + std::to_string(i);
-            if (M.fuse && fused_head_cls(p, whole(feats[i]), Hs[i], Ws[i], c3, i)) continue;
-            if (err) return err;
             int e1 = buf(Hs[i], Ws[i], c3, p + ".e1");
             if (!dwpw(p + ".0.0", p + ".0.1", whole(feats[i]), Hs[i], Ws[i], whole(e1))) {
                 int d1 = buf(Hs[i], Ws[i], chs[i], p + ".d1");
@@ -969,8 +780,6 @@ struct Builder {
         for (int i = 0; i < 3; ++i) {
             size_t first_op = P.ops.size();
             std::string p = "model.23.cv4." + std::to_string(i);
-            if (M.fuse && fused_head_angle(p, whole(feats[i]), Hs[i], Ws[i], c4, i)) continue;
-            if (err) return err;
             int u2 = buf(Hs[i], Ws[i], c4, p + ".u2");
             Slice u1sl = u1s[i];
             if (u1sl.buf < 0) {
@@ -1150,20 +959,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_stem(L, st);
                 break;
             }
-            case OP_FUSED: {
-                FusedLaunch L = op.fused;
-                L.B = B;
-                L.in = tref(P, op.in, boff);
-                if (op.head_level >= 0) {
-                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
-                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
-                } else L.out = tref(P, op.out, boff);
-                e = launch_fused(L, st);
-                break;
-            }
             case OP_ATTN:
                 if (M.f32) { e = launch_attention_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, st); break; }
-                e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, st); break;
+                e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, M.o.attn_mfma, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
     }
@@ -1176,7 +974,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
 // Kept at 2 so that caller stream + side streams + one more user stream still fit the 4 hardware queues.
 static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t main_st) {
     Model &M = *ctx->model;
-    static const int nsplit_cfg = getenv("OBB_FWD_SPLIT") ? std::max(1, std::min(3, atoi(getenv("OBB_FWD_SPLIT")))) : 2;
+    const int nsplit_cfg = std::max(1, std::min(3, ctx->opt.fwd_split));
     int ns = (B >= 32 * nsplit_cfg) ? nsplit_cfg : 1;
     if (ns == 1) return run_forward(ctx, P, tiles, B, head, main_st, 0);
     if (!P.lanes[0]) {
@@ -1235,12 +1033,12 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     if (rc) return rc;
     M->f16 = ctx->opt_f16;
     M->f32 = ctx->opt_f32;
-    M->fuse = getenv("OBB_FUSE") ? atoi(getenv("OBB_FUSE")) != 0 : ctx->opt_fuse;
-    M->tail = getenv("OBB_TAIL") ? atoi(getenv("OBB_TAIL")) != 0 : ctx->opt_tail;
-    M->upfold = !(getenv("OBB_UPFOLD") && atoi(getenv("OBB_UPFOLD")) == 0);
-    if (M->f32) { M->fuse = false; M->tail = false; M->upfold = false; }  // fp32 arithmetic: one kernel per layer, fp32 NHWC buffers
-    M->hmerge = M->tail && !(getenv("OBB_HMERGE") && atoi(getenv("OBB_HMERGE")) == 0);
-    M->bneck = M->tail;  // both swallow intermediate activations: one switch ("tail" = 0 keeps every layer observable)
+    M->o = ctx->opt;
+    M->tail = ctx->opt.tail;
+    M->upfold = ctx->opt.upfold;
+    if (M->f32) { M->tail = false; M->upfold = false; }  // fp32 arithmetic: one kernel per layer, fp32 NHWC buffers
+    M->hmerge = M->tail && ctx->opt.hmerge;
+    M->bneck = M->tail && ctx->opt.bneck;  // both swallow intermediate activations ("tail" = 0 keeps every layer observable)
     if (M->f32) {  // `im.float() / 255`: IEEE division, one table entry per byte value
         std::vector<float> lut32(256);
         for (int v = 0; v < 256; ++v) lut32[v] = (float)v / 255.0f;
@@ -1256,6 +1054,15 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     return OBB_OK;
 }
 
+int obb_model_unload(obb_ctx *ctx, int32_t slot) {
+    OBB_REQUIRE(ctx, ctx && slot >= 0 && slot < 64, "obb_model_unload: bad arguments");
+    OBB_HIP(ctx, hipSetDevice(ctx->device));
+    OBB_HIP(ctx, hipDeviceSynchronize());  // nothing of the model's plans (slabs, weights, graphs) may still be in flight
+    if (slot == ctx->slot) ctx->model.reset();
+    ctx->slots.erase(slot);
+    return OBB_OK;
+}
+
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
     OBB_REQUIRE(ctx, ctx && key, "obb_set_option: bad arguments");
     std::string k(key);
@@ -1265,13 +1072,17 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_f32 = (value == 32);
         return OBB_OK;
     }
-    if (k == "fuse") {  // 1 = LDS-resident layer chains (fused.hip), 0 = one kernel per layer (default; every activation observable); next obb_model_load
-        ctx->opt_fuse = value != 0;
-        return OBB_OK;
-    }
-    if (k == "tail") {  // 1 = fuse the final 1x1 conv of each head branch behind its producer (default), 0 = separate launches; next obb_model_load
-        ctx->opt_tail = value != 0;
-        return OBB_OK;
+    {   // engine switches: 1 = the fused form (default), 0 = its separate launches; all apply to the next obb_model_load, except
+        // "graph", "fwd_split" and "microbatch", which steer how obb_forward issues its launches from the next call on
+        struct { const char *key; bool *flag; } sw[] = {
+            {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
+            {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem},
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"graph", &ctx->opt.graph}};
+        for (auto &e : sw)
+            if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
+        if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
+        if (k == "fwd_split") { OBB_REQUIRE(ctx, value >= 1 && value <= 3, "obb_set_option: fwd_split must be 1..3"); ctx->opt.fwd_split = (int)value; return OBB_OK; }
+        if (k == "microbatch") { OBB_REQUIRE(ctx, value >= 1 && value <= 1024, "obb_set_option: microbatch must be 1..1024"); ctx->opt.microbatch = (int)value; return OBB_OK; }
     }
     if (k == "model_slot") {  // several models per context (dual-scale 128 + 416): select which one load/forward address
         OBB_REQUIRE(ctx, value >= 0 && value < 64, "obb_set_option: model_slot must be in [0, 64)");
@@ -1307,10 +1118,14 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     int rc = get_plan(ctx, h, w, &P);
     if (rc) return rc;
     // The batch is walked in sub-batches: bounds the activation slab (and keeps every 1-D launch inside 32-bit buffer offsets)
-    static const int max_mb = getenv("OBB_MICROBATCH") ? std::max(1, atoi(getenv("OBB_MICROBATCH"))) : 1024;  // measured at B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s (128 / 256: 67 / 79 k with the round-1 kernels)
+    const int max_mb = ctx->opt.microbatch;  // measured at B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s (128 / 256: 67 / 79 k with the round-1 kernels)
     rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
-    static const bool use_graph = !(getenv("OBB_GRAPH") && atoi(getenv("OBB_GRAPH")) == 0);
+    bool use_graph = ctx->opt.graph;
+    {   // inside somebody else's capture (torch.cuda.graph around the registered op) the launches simply join that graph
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) use_graph = false;
+    }
     hipStream_t st = (hipStream_t)s;
     for (int b0 = 0; b0 < B; b0 += max_mb) {
         int nb = std::min<int>(max_mb, B - b0);
@@ -1322,7 +1137,16 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
             OBB_HIP(ctx, hipGraphLaunch(git->second, st));
             continue;
         }
-        bool capture = use_graph && P->seen[key]++ >= 1 && P->graphs.size() < 64;
+        if (P->seen.size() > 4096) P->seen.clear();  // keys are (batch, input pointer, output pointer): a caller that never repeats one must not grow this
+        bool capture = use_graph && P->seen[key]++ >= 1;
+        if (capture && P->graphs.size() >= 64) {  // cache full: drop the oldest half (insertion order), then capture the new key
+            OBB_HIP(ctx, hipStreamSynchronize(st));
+            while (P->graph_order.size() > 32) {
+                auto it = P->graphs.find(P->graph_order.front());
+                if (it != P->graphs.end()) { (void)hipGraphExecDestroy(it->second); P->graphs.erase(it); }
+                P->graph_order.erase(P->graph_order.begin());
+            }
+        }
         if (capture && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); capture = false; }
         rc = run_round(ctx, *P, tp, nb, hp, st);
         if (capture) {
@@ -1332,6 +1156,7 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
                 hipGraphExec_t ge = nullptr;
                 if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
                     P->graphs[key] = ge;
+                    P->graph_order.push_back(key);
                     (void)hipGraphDestroy(g);
                     OBB_HIP(ctx, hipGraphLaunch(ge, st));
                     continue;
@@ -1387,10 +1212,6 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_STEM:
                 snprintf(line, sizeof line, "stem %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem.cin, op.stem.cout, op.Ho, op.Wo, 4, op.macs);
-                break;
-            case OP_FUSED:
-                snprintf(line, sizeof line, "fused %s steps%d tile%dx%d out%dx%d lds%d macs%.0f\n", op.name.c_str(), op.fused.nsteps, op.fused.TH, op.fused.TW,
-                         op.Ho, op.Wo, op.fused.lds_bytes, op.macs);
                 break;
             case OP_ATTN: macs = (double)op.nh * ((double)op.N * op.N * op.kd + (double)op.N * op.N * op.hd);
                 snprintf(line, sizeof line, "attn %s N%d nh%d macs%.0f\n", op.name.c_str(), op.N, op.nh, macs); break;

@@ -224,8 +224,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     t.WC = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
     if (in_u8) t.CK = 4;
     else {
-        static const int ck1 = getenv("OBB_F32_CK1") ? atoi(getenv("OBB_F32_CK1")) : 32;
-        const int cap = ks == 1 ? ck1 : (stride == 2 ? 8 : 16);
+        const int cap = ks == 1 ? 32 : (stride == 2 ? 8 : 16);
         int ck = 4;
         while (ck * 2 <= cap && cin % (ck * 2) == 0) ck *= 2;
         t.CK = ck;

@@ -557,6 +557,11 @@ __global__ __launch_bounds__(256) void k_tile_post(const float *__restrict__ lp,
     angle[i] = a;
 }
 
+__global__ void k_add_offset(int32_t *v, int64_t n, int32_t add) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] += add;
+}
+
 }  // namespace obb
 
 using namespace obb;
@@ -647,17 +652,42 @@ int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep,
     return OBB_OK;
 }
 
+int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n, double thr,
+                         int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
+
 int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int32_t *seg_off,
                        int32_t nseg, int64_t n, double thr, int32_t *order, uint8_t *keep, obb_stream_t s) {
     OBB_REQUIRE(ctx, ctx && nseg >= 0 && n >= 0, "obb_merge_segments: bad arguments");
     if (nseg == 0 || n == 0) return OBB_OK;
     OBB_REQUIRE(ctx, boxes && cls && conf && seg_off && order && keep, "obb_merge_segments: NULL buffer");
+    hipStream_t st = (hipStream_t)s;
     int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
     if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
-    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), (hipStream_t)s));
-    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, (hipStream_t)s, boxes, cls, conf, seg_off, thr,
+    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, thr,
                        order, keep, (int32_t *)nullptr, status);
     OBB_LAUNCH_CHECK(ctx);
+    if (n <= kSegMax) return OBB_OK;  // no segment can be longer than the LDS-resident kernel takes
+    // Segments above kSegMax rows were flagged and left untouched by the kernel (a tile with more than 512 detections: max_det > 512, or
+    // a foreign model without a cap): those go through the dense path of obb_merge_detections, one by one.  (synchronises, 4 bytes;
+    // skipped inside a stream capture, where the caller must keep segments within 512 rows)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return OBB_OK;
+    int32_t flagged = 0;
+    OBB_HIP(ctx, hipMemcpyAsync(&flagged, status, sizeof flagged, hipMemcpyDeviceToHost, st));
+    OBB_HIP(ctx, hipStreamSynchronize(st));
+    if (!flagged) return OBB_OK;
+    std::vector<int32_t> off((size_t)nseg + 1);
+    OBB_HIP(ctx, hipMemcpy(off.data(), seg_off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < nseg; ++k) {
+        const int64_t lo = off[k], len = (int64_t)off[k + 1] - lo;
+        if (len <= kSegMax) continue;
+        OBB_REQUIRE(ctx, lo >= 0 && lo + len <= n, "obb_merge_segments: segment %d out of range", k);
+        int rc = obb_merge_detections(ctx, boxes + 8 * lo, cls + lo, conf + lo, len, thr, order + lo, keep + lo, nullptr, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_add_offset, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, order + lo, len, (int32_t)lo);  // local -> global rows
+        OBB_LAUNCH_CHECK(ctx);
+    }
     return OBB_OK;
 }
 

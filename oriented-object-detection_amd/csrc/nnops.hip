@@ -405,9 +405,8 @@ static hipError_t launch_attention_t(const TensorRef &qkv, const TensorRef &out,
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool f16, hipStream_t st) {
+hipError_t launch_attention(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool f16, bool use_mfma, hipStream_t st) {
     if (kd != 32 || hd != 64) return hipErrorInvalidValue;  // head_dim is 64 for every YOLO11 scale (heads = c/64)
-    static const bool use_mfma = !(getenv("OBB_ATTN_MFMA") && atoi(getenv("OBB_ATTN_MFMA")) == 0);
     if (use_mfma && N <= 192 && N >= 1) {
         const int nks = ((N + 15) / 16 + 1) / 2;
         size_t lds_m = (size_t)nks * 32 * 80 + (size_t)nks * 4 * 1024;

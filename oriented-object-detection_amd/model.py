@@ -87,12 +87,17 @@ class YOLO:
         self.names = names or {}
         self._load()
 
-    _next_slot = {}  # per device: every YOLO object owns one model slot of the device's libobbhip context
+    _next_slot = {}   # per device: every YOLO object owns one model slot of the device's libobbhip context ...
+    _free_slots = {}  # ... and hands it back in close() / __del__ (the library keeps 64 slots per context)
 
     def _load(self):
         idx = self.device.index
-        self._slot = YOLO._next_slot.get(idx, 0)
-        YOLO._next_slot[idx] = self._slot + 1
+        free = YOLO._free_slots.setdefault(idx, [])
+        if free:
+            self._slot = free.pop()
+        else:
+            self._slot = YOLO._next_slot.get(idx, 0)
+            YOLO._next_slot[idx] = self._slot + 1
         with torch.cuda.device(self.device):
             ops.select_model(self._slot, self.device)
             ops.model_load(self._blob, self.device, self.precision)
@@ -100,7 +105,24 @@ class YOLO:
         self.nc, self.ch = info["nc"], info["ch"]
 
     def _ensure_active(self):
+        if self._slot is None:
+            raise RuntimeError("YOLO: this model has been closed")
         ops.select_model(self._slot, self.device)
+
+    def close(self):
+        """Releases the weights, activation slabs and captured graphs of this model on the device; the object is unusable afterwards."""
+        slot, self._slot = getattr(self, "_slot", None), None
+        if slot is None:
+            return
+        try:
+            with torch.cuda.device(self.device):
+                ops.model_unload(slot, self.device)
+            YOLO._free_slots.setdefault(self.device.index, []).append(slot)
+        except Exception:  # interpreter shutdown: the context may already be gone
+            pass
+
+    def __del__(self):
+        self.close()
 
     # ------------------------------------------------------------------ batched device API
     def predict_tiles(self, tiles, conf=0.25, iou=0.7, max_det=300):

@@ -1,14 +1,23 @@
-"""Tensor-level bindings of the C-ABI: torch tensors supply device memory and the current HIP stream, nothing else.
+"""PyTorch-ROCm custom ops over the C-ABI of libobbhip.so (SURVEY.md section 8(b) "Registration").
 
-Every function here launches hand-written HIP kernels from libobbhip.so; inputs must be CUDA(=HIP) tensors.
+Every device entry point of include/obbhip.h is registered with the torch dispatcher as `torch.ops.obbhip.<name>` through
+`torch.library.custom_op` (device type "cuda" = HIP on ROCm: there is no CPU implementation, a CPU tensor raises).  The registered
+form takes the caller's tensors only -- inputs, and outputs as pre-allocated tensors it mutates -- and launches the hand-written HIP
+kernels on torch's CURRENT stream, so the ops compose with torch streams, events and `torch.cuda.graph` capture.  PyTorch supplies
+device memory and streams, nothing else; no Triton, no multi-backend dispatch.
+
+The plain functions below (`forward`, `decode_nms`, `merge_detections`, ...) are the convenience layer the rest of the package
+uses: they allocate the outputs and call `torch.ops.obbhip.*`.
 """
 import ctypes as C
+from typing import List, Optional
 
 import torch
 
 from . import _lib
 
 _ctx = {}
+T = torch.Tensor
 
 
 def ctx(device=None):
@@ -47,8 +56,124 @@ def _call(name, c, *args):
     _lib.check(getattr(_lib.lib(), name)(c, *args), c)
 
 
-# ---------------------------------------------------------------- S2 polygon IoU
+def _op(name, mutates):
+    return torch.library.custom_op(f"obbhip::{name}", mutates_args=mutates, device_types="cuda")
 
+
+# ================================================================ registered ops (torch.ops.obbhip.*)
+# ---------------------------------------------------------------- S2 polygon IoU (Detect_OBB.py:144-154)
+@_op("poly_iou_pairs", ("out",))
+def _poly_iou_pairs(a: T, b: T, out: T) -> None:
+    _call("obb_poly_iou_pairs", ctx(a.device), _p(a), _p(b), a.shape[0], _p(out), _stream())
+
+
+@_op("poly_iou_matrix", ("out",))
+def _poly_iou_matrix(a: T, cls_a: Optional[T], b: T, cls_b: Optional[T], out: T) -> None:
+    _call("obb_poly_iou_matrix", ctx(a.device), _p(a), _p(cls_a), a.shape[0], _p(b), _p(cls_b), b.shape[0], _p(out), _stream())
+
+
+@_op("points_in_quads", ("out",))
+def _points_in_quads(pts: T, cls_p: Optional[T], quads: T, cls_q: Optional[T], out: T) -> None:
+    _call("obb_points_in_quads", ctx(pts.device), _p(pts), _p(cls_p), pts.shape[0], _p(quads), _p(cls_q), quads.shape[0], _p(out), _stream())
+
+
+@_op("build_multich", ("out",))
+def _build_multich(bgr: T, out: T) -> None:
+    _call("obb_build_multich", ctx(bgr.device), _p(bgr), bgr.shape[0], bgr.shape[1], bgr.shape[2], _p(out), _stream())
+
+
+# ---------------------------------------------------------------- S3 merge_detections (Detect_OBB.py:176-200)
+@_op("sort_desc_stable", ("order",))
+def _sort_desc_stable(key: T, order: T) -> None:
+    _call("obb_sort_desc_stable", ctx(key.device), _p(key), key.shape[0], _p(order), _stream())
+
+
+@_op("nms_mask", ("mask",))
+def _nms_mask(boxes: T, cls: T, thr: float, mask: T) -> None:
+    _call("obb_nms_mask", ctx(boxes.device), _p(boxes), _p(cls), boxes.shape[0], float(thr), _p(mask), _stream())
+
+
+@_op("nms_reduce", ("keep", "n_keep"))
+def _nms_reduce(mask: T, n: int, keep: T, n_keep: T) -> None:
+    _call("obb_nms_reduce", ctx(mask.device), _p(mask), n, _p(keep), _p(n_keep), _stream())
+
+
+@_op("merge_detections", ("order", "keep", "n_keep"))
+def _merge_detections(boxes: T, cls: T, conf: T, thr: float, order: T, keep: T, n_keep: T) -> None:
+    _call("obb_merge_detections", ctx(boxes.device), _p(boxes), _p(cls), _p(conf), boxes.shape[0], float(thr), _p(order), _p(keep), _p(n_keep), _stream())
+
+
+@_op("merge_segments", ("order", "keep"))
+def _merge_segments(boxes: T, cls: T, conf: T, seg_off: T, thr: float, order: T, keep: T) -> None:
+    _call("obb_merge_segments", ctx(boxes.device), _p(boxes), _p(cls), _p(conf), _p(seg_off), seg_off.shape[0] - 1, boxes.shape[0], float(thr), _p(order),
+          _p(keep), _stream())
+
+
+# ---------------------------------------------------------------- S4 consensus (Detect_OBB.py:347-423)
+@_op("consensus", ("out_idx", "n_out"))
+def _consensus(boxes: T, cls: T, conf: T, offsets: List[int], iou_partner: float, cons_low: float, cons_high: float, out_idx: T, n_out: T) -> None:
+    off = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
+    _call("obb_consensus", ctx(boxes.device), _p(boxes), _p(cls), _p(conf), off, len(offsets) - 1, float(iou_partner), float(cons_low), float(cons_high),
+          _p(out_idx), _p(n_out), _stream())
+
+
+# ---------------------------------------------------------------- S5 detect_symbols pieces (Detect_OBB.py:202-266)
+@_op("tile_postprocess", ("gboxes", "angle", "inside"))
+def _tile_postprocess(local_pts: T, cls: T, det_tile: T, rects: T, margin: int, strike_cls: int, gboxes: T, angle: T, inside: T) -> None:
+    _call("obb_tile_postprocess", ctx(local_pts.device), _p(local_pts), _p(cls), _p(det_tile), local_pts.shape[0], _p(rects), rects.shape[0], int(margin),
+          int(strike_cls), _p(gboxes), _p(angle), _p(inside), _stream())
+
+
+@_op("gather_tiles", ("out",))
+def _gather_tiles(image: T, rects: T, tile: int, out: T) -> None:
+    H, W, Cc = image.shape
+    _call("obb_gather_tiles", ctx(image.device), _p(image), H, W, Cc, _p(rects), rects.shape[0], tile, _p(out), _stream())
+
+
+@_op("letterbox", ("out",))
+def _letterbox(image: T, x: int, y: int, x2: int, y2: int, imgsz: int, out: T) -> None:
+    H, W, Cc = image.shape
+    _call("obb_letterbox", ctx(image.device), _p(image), H, W, Cc, int(x), int(y), int(x2), int(y2), int(imgsz), _p(out), out.shape[0], out.shape[1], _stream())
+
+
+# ---------------------------------------------------------------- S1 model (Detect_OBB.py:26, 81-83, 228-231)
+@_op("forward", ("head",))
+def _forward(tiles: T, head: T) -> None:
+    B, h, w, _ = tiles.shape
+    _call("obb_forward", ctx(tiles.device), _p(tiles), B, h, w, _p(head), _stream())
+
+
+@_op("decode", ("pred",))
+def _decode(head: T, h: int, w: int, pred: T) -> None:
+    _call("obb_decode", ctx(head.device), _p(head), head.shape[0], h, w, _p(pred), _stream())
+
+
+@_op("decode_nms", ("det", "count"))
+def _decode_nms(head: T, h: int, w: int, conf: float, iou: float, max_det: int, det: T, count: T) -> None:
+    _call("obb_decode_nms", ctx(head.device), _p(head), head.shape[0], h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
+
+
+@_op("probiou_nms", ("order", "keep"))
+def _probiou_nms(boxes: T, scores: T, iou: float, order: T, keep: T) -> None:
+    _call("obb_probiou_nms", ctx(boxes.device), _p(boxes), _p(scores), boxes.shape[0], float(iou), _p(order), _p(keep), _stream())
+
+
+@_op("results", ("xywhr", "pts"))
+def _results(det: T, lb: Optional[T], xywhr: T, pts: T) -> None:
+    _call("obb_results", ctx(det.device), _p(det), _p(lb), det.shape[0], _p(xywhr), _p(pts), _stream())
+
+
+@_op("debug_activation", ("out",))
+def _debug_activation(name: str, B: int, h: int, w: int, out: T) -> None:
+    n = C.c_int64(0)
+    shp = (C.c_int32 * 3)()
+    _call("obb_debug_activation", ctx(out.device), h, w, B, name.encode(), _p(out), out.numel(), C.byref(n), shp, _stream())
+
+
+_O = torch.ops.obbhip
+
+
+# ================================================================ convenience layer (allocates the outputs)
 def poly_iou_pairs(a, b):
     """a, b: [M,8] float64 -> [M] float64   (compute_polygon_iou per row, Detect_OBB.py:144)"""
     a = _chk(a, torch.float64, "a").reshape(-1, 8)
@@ -56,7 +181,7 @@ def poly_iou_pairs(a, b):
     if a.shape != b.shape:
         raise ValueError("poly_iou_pairs: shape mismatch")
     out = torch.empty(a.shape[0], dtype=torch.float64, device=a.device)
-    _call("obb_poly_iou_pairs", ctx(a.device), _p(a), _p(b), a.shape[0], _p(out), _stream())
+    _O.poly_iou_pairs(a, b, out)
     return out
 
 
@@ -67,7 +192,7 @@ def poly_iou_matrix(a, b, cls_a=None, cls_b=None):
         _chk(cls_a, torch.int32, "cls_a")
         _chk(cls_b, torch.int32, "cls_b")
     out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=a.device)
-    _call("obb_poly_iou_matrix", ctx(a.device), _p(a), _p(cls_a), a.shape[0], _p(b), _p(cls_b), b.shape[0], _p(out), _stream())
+    _O.poly_iou_matrix(a, cls_a, b, cls_b, out)
     return out
 
 
@@ -80,7 +205,7 @@ def build_multich(bgr_tiles, out=None):
     else:
         _chk(out, torch.uint8, "out")
         assert tuple(out.shape) == (t.shape[0], t.shape[1], t.shape[2], 4)
-    _call("obb_build_multich", ctx(t.device), _p(t), t.shape[0], t.shape[1], t.shape[2], _p(out), _stream())
+    _O.build_multich(t, out)
     return out
 
 
@@ -92,16 +217,14 @@ def points_in_quads(pts, quads, cls_p=None, cls_q=None):
         _chk(cls_p, torch.int32, "cls_p")
         _chk(cls_q, torch.int32, "cls_q")
     out = torch.zeros((pts.shape[0], quads.shape[0]), dtype=torch.uint8, device=pts.device)
-    _call("obb_points_in_quads", ctx(pts.device), _p(pts), _p(cls_p), pts.shape[0], _p(quads), _p(cls_q), quads.shape[0], _p(out), _stream())
+    _O.points_in_quads(pts, cls_p, quads, cls_q, out)
     return out
 
-
-# ---------------------------------------------------------------- S3 merge_detections
 
 def sort_desc_stable(key):
     key = _chk(key, torch.float64, "key")
     order = torch.empty(key.shape[0], dtype=torch.int32, device=key.device)
-    _call("obb_sort_desc_stable", ctx(key.device), _p(key), key.shape[0], _p(order), _stream())
+    _O.sort_desc_stable(key, order)
     return order
 
 
@@ -111,14 +234,14 @@ def nms_mask(boxes_sorted, cls_sorted, thr):
     n = b.shape[0]
     w = (n + 63) // 64
     mask = torch.zeros((w, max(n, 1)), dtype=torch.int64, device=b.device)
-    _call("obb_nms_mask", ctx(b.device), _p(b), _p(c), n, float(thr), _p(mask), _stream())
+    _O.nms_mask(b, c, float(thr), mask)
     return mask
 
 
 def nms_reduce(mask, n):
     keep = torch.zeros(n, dtype=torch.uint8, device=mask.device)
     nk = torch.zeros(1, dtype=torch.int32, device=mask.device)
-    _call("obb_nms_reduce", ctx(mask.device), _p(mask), n, _p(keep), _p(nk), _stream())
+    _O.nms_reduce(mask, n, keep, nk)
     return keep, nk
 
 
@@ -131,12 +254,13 @@ def merge_detections(boxes, cls, conf, thr):
     order = torch.empty(n, dtype=torch.int32, device=b.device)
     keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
     nk = torch.zeros(1, dtype=torch.int32, device=b.device)
-    _call("obb_merge_detections", ctx(b.device), _p(b), _p(c), _p(s), n, float(thr), _p(order), _p(keep), _p(nk), _stream())
+    _O.merge_detections(b, c, s, float(thr), order, keep, nk)
     return order, keep, nk
 
 
 def merge_segments(boxes, cls, conf, seg_off, thr):
-    """Batched per-tile merge (Detect_OBB.py:264).  seg_off int32[nseg+1] device.  Segments must be <= 512 rows."""
+    """Batched per-tile merge (Detect_OBB.py:264).  seg_off int32[nseg+1] device.  Segments of any length (the library takes long
+    ones through its dense path)."""
     b = _chk(boxes, torch.float64, "boxes").reshape(-1, 8)
     c = _chk(cls, torch.int32, "cls")
     s = _chk(conf, torch.float64, "conf")
@@ -144,26 +268,19 @@ def merge_segments(boxes, cls, conf, seg_off, thr):
     n = b.shape[0]
     order = torch.empty(n, dtype=torch.int32, device=b.device)
     keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
-    _call("obb_merge_segments", ctx(b.device), _p(b), _p(c), _p(s), _p(so), so.shape[0] - 1, n, float(thr), _p(order), _p(keep),
-          _stream())
+    _O.merge_segments(b, c, s, so, float(thr), order, keep)
     return order, keep
 
-
-# ---------------------------------------------------------------- S4 consensus
 
 def consensus(boxes, cls, conf, offsets, iou_partner=0.40, cons_low=0.25, cons_high=0.70):
     b = _chk(boxes, torch.float64, "boxes").reshape(-1, 8)
     c = _chk(cls, torch.int32, "cls")
     s = _chk(conf, torch.float64, "conf")
-    off = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
     out = torch.empty(max(1, b.shape[0]), dtype=torch.int32, device=b.device)
     nout = torch.zeros(1, dtype=torch.int32, device=b.device)
-    _call("obb_consensus", ctx(b.device), _p(b), _p(c), _p(s), off, len(offsets) - 1, float(iou_partner), float(cons_low),
-          float(cons_high), _p(out), _p(nout), _stream())
+    _O.consensus(b, c, s, [int(o) for o in offsets], float(iou_partner), float(cons_low), float(cons_high), out, nout)
     return out, nout
 
-
-# ---------------------------------------------------------------- S5 detect_symbols pieces
 
 def tile_grid(H, W, tile, overlap):
     """Host helper -> int32 numpy [ntiles,4] (x, y, x2, y2) in reference visiting order."""
@@ -184,14 +301,13 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
     gb = torch.empty((n, 8), dtype=torch.float64, device=lp.device)
     ang = torch.empty(n, dtype=torch.float64, device=lp.device)
     ins = torch.empty(n, dtype=torch.uint8, device=lp.device)
-    _call("obb_tile_postprocess", ctx(lp.device), _p(lp), _p(c), _p(dt), n, _p(r), r.shape[0], int(margin), int(strike_cls),
-          _p(gb), _p(ang), _p(ins), _stream())
+    _O.tile_postprocess(lp, c, dt, r, int(margin), int(strike_cls), gb, ang, ins)
     return gb, ang, ins
 
 
-# ---------------------------------------------------------------- S1 model
-
 PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016, "f32": 32, "fp32": 32}
+# engine switches of obb_set_option (each restores the separate launches of one fused form; used by the A/B parity tests)
+MODEL_OPTIONS = ("fuse", "tail", "tail16", "bneck", "bneck_cv2", "c3kimg", "dwpw", "upfold", "stem", "hmerge", "sppf_fuse", "attn_mfma", "graph")
 
 
 def select_model(slot, device=None):
@@ -199,18 +315,27 @@ def select_model(slot, device=None):
     _call("obb_set_option", ctx(device), b"model_slot", int(slot))
 
 
-def model_load(blob, device=None, precision="f16", fuse=False, tail=True):
-    """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: 16-bit storage type.
-    fuse=True runs the 104x104 C3k2 block and the class / angle branches of the head as LDS-resident layer chains (fused.hip)
-    instead of one kernel per layer (the default, which is currently faster and keeps every activation observable).
-    tail=False keeps the final 1x1 conv of each head branch a separate launch (default: fused behind its producer, whose own
-    output then never reaches HBM)."""
+def model_load(blob, device=None, precision="f16", fuse=False, tail=True, **options):
+    """blob: bytes of an "OBBW" weight blob (host), loaded into the active model slot.  precision: "f16" / "bf16" = 16-bit storage with
+    fp32 accumulation, "f32" = fp32 arithmetic end to end (what the reference computes; one kernel per layer).
+    tail=False keeps the final 1x1 conv of each head branch a separate launch and turns every other intermediate-swallowing fusion off
+    (every layer observable).  Further keyword switches (MODEL_OPTIONS, all default on except `fuse`) disable single fused forms:
+    tail16, bneck, bneck_cv2, c3kimg, dwpw, upfold, stem, hmerge, sppf_fuse, attn_mfma."""
     c = ctx(device)
     _call("obb_set_option", c, b"precision", PRECISIONS[precision])
     _call("obb_set_option", c, b"fuse", 1 if fuse else 0)
     _call("obb_set_option", c, b"tail", 1 if tail else 0)
+    for k in MODEL_OPTIONS[2:]:
+        _call("obb_set_option", c, k.encode(), 1 if options.pop(k, True) else 0)
+    if options:
+        raise TypeError(f"model_load: unknown options {sorted(options)}")
     buf = (C.c_char * len(blob)).from_buffer_copy(blob)
     _call("obb_model_load", c, buf, len(blob))
+
+
+def model_unload(slot, device=None):
+    """Frees the model of `slot` (weights, plans, activation slabs, captured graphs) after a device synchronisation."""
+    _call("obb_model_unload", ctx(device), int(slot))
 
 
 def model_info(h, w, device=None):
@@ -236,7 +361,8 @@ def forward(tiles, out=None):
         head = _chk(out, torch.float32, "out")
     else:
         head = torch.zeros(shape, dtype=torch.float32, device=t.device)
-    _call("obb_forward", ctx(t.device), _p(t), B, h, w, _p(head), _stream())
+    if B:
+        _O.forward(t, head)
     return head  # rows padded to a multiple of 4 floats; [..., :64+nc+1] are the logits
 
 
@@ -266,7 +392,7 @@ def debug_activation(name, B, h, w, device=None):
     shp = (C.c_int32 * 3)()
     _call("obb_debug_activation", c, h, w, B, name.encode(), None, 0, C.byref(n), shp, _stream())
     out = torch.empty((B, shp[0], shp[1], shp[2]), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-    _call("obb_debug_activation", c, h, w, B, name.encode(), _p(out), out.numel(), C.byref(n), shp, _stream())
+    _O.debug_activation(name, B, h, w, out)
     return out
 
 
@@ -275,7 +401,7 @@ def decode(head, h, w):
     hd = _padded_head(_chk(head, torch.float32, "head"))
     B, A, _ = hd.shape
     pred = torch.empty((B, A, 4 + model_info(h, w, hd.device)["nc"] + 1), dtype=torch.float32, device=hd.device)
-    _call("obb_decode", ctx(hd.device), _p(hd), B, h, w, _p(pred), _stream())
+    _O.decode(hd, h, w, pred)
     return pred
 
 
@@ -285,7 +411,8 @@ def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300):
     B = hd.shape[0]
     det = torch.zeros((B, max_det, 7), dtype=torch.float32, device=hd.device)
     count = torch.zeros(B, dtype=torch.int32, device=hd.device)
-    _call("obb_decode_nms", ctx(hd.device), _p(hd), B, h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
+    if B:
+        _O.decode_nms(hd, h, w, float(conf), float(iou), int(max_det), det, count)
     return det, count
 
 
@@ -295,7 +422,7 @@ def probiou_nms(boxes, scores, iou):
     n = b.shape[0]
     order = torch.empty(n, dtype=torch.int32, device=b.device)
     keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
-    _call("obb_probiou_nms", ctx(b.device), _p(b), _p(s), n, float(iou), _p(order), _p(keep), _stream())
+    _O.probiou_nms(b, s, float(iou), order, keep)
     return order, keep
 
 
@@ -307,7 +434,7 @@ def results(det, lb=None):
         lb = _chk(lb, torch.float32, "lb").reshape(-1, 3)
     xywhr = torch.empty((n, 5), dtype=torch.float32, device=d.device)
     pts = torch.empty((n, 8), dtype=torch.float32, device=d.device)
-    _call("obb_results", ctx(d.device), _p(d), _p(lb), n, _p(xywhr), _p(pts), _stream())
+    _O.results(d, lb, xywhr, pts)
     return xywhr, pts
 
 
@@ -317,7 +444,7 @@ def gather_tiles(image, rects, tile):
     r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
     H, W, Cc = img.shape
     out = torch.empty((r.shape[0], tile, tile, Cc), dtype=torch.uint8, device=img.device)
-    _call("obb_gather_tiles", ctx(img.device), _p(img), H, W, Cc, _p(r), r.shape[0], tile, _p(out), _stream())
+    _O.gather_tiles(img, r, int(tile), out)
     return out
 
 
@@ -341,6 +468,5 @@ def letterbox(image, x, y, x2, y2, imgsz):
     H, W, Cc = img.shape
     p = letterbox_shape(y2 - y, x2 - x, imgsz)
     out = torch.empty((p["out_h"], p["out_w"], Cc), dtype=torch.uint8, device=img.device)
-    _call("obb_letterbox", ctx(img.device), _p(img), H, W, Cc, int(x), int(y), int(x2), int(y2), int(imgsz), _p(out), p["out_h"],
-          p["out_w"], _stream())
+    _O.letterbox(img, int(x), int(y), int(x2), int(y2), int(imgsz), out)
     return out, p

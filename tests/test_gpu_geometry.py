@@ -136,6 +136,26 @@ def test_merge_segments_vs_oracle(ops):
         assert np.array_equal(keep[off[k]:off[k + 1]], ek), k
 
 
+def test_merge_segments_longer_than_the_lds_kernel(ops):
+    """a tile with more than 512 detections (max_det > 512, or a foreign model without a cap): such segments used to be dropped silently;
+    they now go through the dense path, the short ones around them through the LDS kernel, all in one call"""
+    sizes = [40, 513, 0, 1500, 512, 7]
+    bs, cs, ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        b, c, s, _ = synth.make_dets(90 + k, n, extent=600.0) if n else (np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros(0), None)
+        bs.append(b); cs.append(c); ss.append(s); off.append(off[-1] + n)
+    B, Cc, S = np.concatenate(bs), np.concatenate(cs), np.concatenate(ss)
+    order, keep = ops.merge_segments(dev(B, torch.float64), dev(Cc, torch.int32), dev(S, torch.float64), dev(np.array(off), torch.int32), 0.4)
+    order, keep = order.cpu().numpy(), keep.cpu().numpy()
+    for k, n in enumerate(sizes):
+        if n == 0:
+            continue
+        eo, ek = og.merge_arrays(bs[k], cs[k], ss[k], 0.4)
+        assert np.array_equal(order[off[k]:off[k + 1]], eo + off[k]), k
+        assert np.array_equal(keep[off[k]:off[k + 1]], ek), k
+        assert 0 < ek.sum() < n or n < 3
+
+
 def test_consensus_matches_reference_goldens(ops, ref_vectors):
     rv = ref_vectors
     for ci in rv["cons_cases"]:

@@ -2,7 +2,7 @@
 """Headline benchmark: 416-px tiles/sec of the Detect_OBB.py hot path on MI355X (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch (default 1024) of synthetic 416x416x3 tiles that are already resident in HBM
-(config[1]: YOLOv11n-OBB 3-ch 416x416 tiled inference, single scale):
+(configs[1]: YOLOv11n-OBB 3-ch 416x416 tiled inference, single scale):
     uint8 tiles -> fused preprocess + YOLO11n-OBB forward (MFMA implicit-GEMM convs) -> decode -> ProbIoU Fast-NMS
     -> result construction -> border filter -> per-tile polygon-IoU merge -> [N>1: RCCL all-gather of survivor records]
     -> final whole-batch polygon-IoU merge (the fusion step of process_image).
@@ -10,17 +10,23 @@ Nothing is cached or skipped between steps; consecutive steps are software-pipel
 k+1 overlaps the post-processing of step k; --no-pipeline disables it).  With --gpus N every rank processes its own batch (weak
 scaling) and the survivors of all ranks are exchanged every step exactly as the multi-GPU tiler does.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (MFMA, for the conv kernel family: algorithmic FLOPs of
-the forward / HIP-event time of the forward) and "cpu_baseline" (the CPU restatement of the same path, bounded sample).
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one process per GPU) when it is not already running under
+a launcher; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the ranks it is given.
+
+Prints ONE JSON line (rank 0).  Objects beside the contract fields:
+  "roofline"      MFMA roofline of the forward (algorithmic FLOPs / HIP-event time), plus "postproc": HBM-side figures of decode + NMS
+  "f32"           the same workload in fp32 arithmetic (obb_set_option precision 32 -- what the reference computes), with its own roofline
+                  (exact-f32 MFMA peak 157.3 TFLOP/s)
+  "also"          the other BASELINE configs timed the same way: dual-scale (configs[2]) and 4-channel input (configs[3], per GPU)
+  "cpu_baseline"  the CPU restatement of the same path (bounded sample; baseline only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,11 +34,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_TILE = 2 * 1392703312  # YOLO11n-OBB nc=12, 3x416x416
 FLOP_PER_TILE_4CH = 2797866656  # same table, 4-channel input (BASELINE configs[3])
-PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+FLOP_PER_TILE_128 = 262767104   # 3x128x128
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md chip table
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 1024)), help="tiles per GPU per step (SURVEY 8(d): B in {1, 16, 64, 256, 1024})")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f32"], help="arithmetic of the HEADLINE line (the f32 figure is reported beside it by default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32 / dual-scale / 4-channel measurements beside the headline")
+    ap.add_argument("--channels", type=int, default=3, choices=[3, 4], help="4 = BASELINE configs[3] as the headline: every step also builds the RGB + DT-edge "
+                    "input of a 4-channel checkpoint from the BGR tiles (build_multich) before the forward")
+    return ap.parse_args()
 
 
 def synthetic_rects(B, tile=416, step=316, cols=16):
-    """tile rectangles of a virtual map scanned with the reference's stride (416 - 100)"""
+    """tile rectangles of a virtual map scanned with the reference's stride (tile - overlap)"""
+    import numpy as np
     r = np.zeros((B, 4), np.int32)
     for t in range(B):
         x, y = (t % cols) * step, (t // cols) * step
@@ -43,6 +66,8 @@ def synthetic_rects(B, tile=416, step=316, cols=16):
 def cpu_baseline(budget_s=15.0):
     """The CPU restatement of the same path (oracle/: torch-CPU fp32 forward, one tile per call like the reference,
     + oracle post-processing + C geometry), timed on this box's host cores on a bounded sample."""
+    import numpy as np
+    import torch
     from oracle import pipeline as opl
     from oracle.yolo11_obb import Yolo11OBB
     torch.set_num_threads(min(os.cpu_count() or 1, 32))  # more threads only add synchronisation cost on these small convolutions
@@ -64,22 +89,30 @@ def cpu_baseline(budget_s=15.0):
             "sample": f"{n} synthetic 416x416x3 tiles, one model call per tile (reference loop), torch-CPU fp32 + C geometry, {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 1024)), help="tiles per GPU per step (SURVEY 8(d): B in {1, 16, 64, 256, 1024})")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--channels", type=int, default=3, choices=[3, 4], help="4 = BASELINE configs[3]: every step also builds the RGB + DT-edge "
-                    "input of a 4-channel checkpoint from the BGR tiles (build_multich) before the forward; not the headline configuration")
-    args = ap.parse_args()
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves.  The parent never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to record a scaling point with a wrong n_gpus")
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
     # one process per GPU; OBB_FORCE_DEVICE / OBB_DIST_BACKEND exist only to rehearse the N > 1 code path on a 1-GPU box (gloo)
@@ -101,139 +134,236 @@ def main():
     from oriented_object_detection_amd import ops
     from oriented_object_detection_amd.model import YOLO
 
-    if rank == 0:
-        wpath = make_weights.ensure("n", 12, args.channels, 0)
-    if world > 1:
-        dist.barrier()
-    wpath = make_weights.path_for("n", 12, args.channels, 0)
-    model = YOLO(wpath, imgsz=416, precision=args.precision)
-    cfg = D.Config(tile_sizes=(416,), overlaps=(100,))
+    def weights(ch, seed):
+        if rank == 0:
+            make_weights.ensure("n", 12, ch, seed)
+        if world > 1:
+            dist.barrier()
+        return make_weights.path_for("n", 12, ch, seed)
+
     B = args.batch
-    tiles = torch.as_tensor(np.random.default_rng(rank).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).to(dev)
-    rects = synthetic_rects(B * world)
-    rects_dev = torch.as_tensor(rects).to(dev)
-    tile_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
-    fwd_ev = []
-
-    # Two HIP streams, software-pipelined over steps: the forward of step k+1 (whole chip, HBM/MFMA bound) is enqueued before the
-    # host starts the post-processing of step k (per-tile NMS / merge kernels: latency bound, a few workgroups, host-visible counts).
-    # Every step still performs all of its work inside the timed region; nothing is reused between steps (heads are double-buffered).
     s_fwd, s_post = torch.cuda.Stream(), torch.cuda.Stream()
-    head_bufs = [torch.zeros((B, 3549, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
-    # 4-channel mode: the input builder runs on the forward's stream in front of it (measured: on a stream of its own, under the previous
-    # step's forward, it costs more than it hides -- 70.3 k vs 72.4 k tiles/s: the forward's two chains and the post-processing stream
-    # already occupy the hardware queues)
-    tiles4 = torch.zeros((B, 416, 416, 4), dtype=torch.uint8, device=dev) if args.channels == 4 else None
-    md = cfg.max_det
 
-    def launch_forward(k, timed):
-        with torch.cuda.stream(s_fwd):
-            model._ensure_active()
+    class Scale:
+        """one tile size of a workload: the model, its resident synthetic tiles, double-buffered heads, tile rectangles"""
+
+        def __init__(self, model, px, n, seed, rects, tile_ids, channels=3):
+            self.model, self.px, self.n = model, px, n
+            self.tiles = torch.as_tensor(np.random.default_rng(seed).integers(0, 256, (n, px, px, 3), dtype=np.uint8)).to(dev)
+            # 4-channel mode: the input builder runs on the forward's stream in front of it (on a stream of its own, under the previous
+            # step's forward, it costs more than it hides: the forward's two chains and the post-processing stream already occupy the queues)
+            self.tiles4 = torch.zeros((n, px, px, 4), dtype=torch.uint8, device=dev) if channels == 4 else None
+            A = ops.model_info(px, px)["anchors"]
+            self.heads = [torch.zeros((n, A, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
+            self.rects_dev = torch.as_tensor(rects).to(dev)
+            self.tile_ids = tile_ids
+            self.cfg = D.Config(tile_sizes=(px,), overlaps=(100 if px > 128 else 30,))
+            self.ev = []
+
+        def forward(self, k, timed):  # on s_fwd
+            self.model._ensure_active()
             e0, e1 = torch.cuda.Event(enable_timing=timed), torch.cuda.Event(enable_timing=timed)
-            if tiles4 is not None:
-                ops.build_multich(tiles, out=tiles4)  # inside the step, outside the forward's event pair
+            if self.tiles4 is not None:
+                ops.build_multich(self.tiles, out=self.tiles4)  # inside the step, outside the forward's event pair
             e0.record()
-            head = ops.forward(tiles if tiles4 is None else tiles4, out=head_bufs[k % 2])
+            head = ops.forward(self.tiles if self.tiles4 is None else self.tiles4, out=self.heads[k % 2])
             e1.record()
-        if timed:
-            fwd_ev.append((e0, e1))
-        return head, e1
+            if timed:
+                self.ev.append((e0, e1))
+            return head
 
-    def postprocess(head, ready):
-        with torch.cuda.stream(s_post):
-            s_post.wait_event(ready)
-            det, cnt = ops.decode_nms(head, 416, 416, cfg.conf_predict, cfg.iou_nms, md)
+        def records(self, head):  # on s_post: decode -> Fast-NMS -> results -> border filter -> per-tile merge
+            self.model._ensure_active()
+            md = self.cfg.max_det
+            det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md)
             valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
             rows = torch.nonzero(valid).squeeze(1)
-            if rows.numel():
-                d = det.reshape(-1, 7)[rows].contiguous()
-                slot = (rows // md).long()
-                _, pts = ops.results(d, None)
-                rec = D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), tile_ids[slot].contiguous(), rects_dev, cfg, 416)
-            else:
-                rec = D.TileRecords.empty(dev)
-            if world > 1:
-                rec = DD.all_gather_records(rec)
-            ds = D.records_to_detset(rec, rects_dev, cfg, 416)
-            merged, _ = D.merge_detections_device(ds, cfg.iou_threshold)
-            done = torch.cuda.Event()
-            done.record()
-        return len(rec), len(merged), done
+            if not rows.numel():
+                return D.TileRecords.empty(dev)
+            d = det.reshape(-1, 7)[rows].contiguous()
+            slot = (rows // md).long()
+            _, pts = ops.results(d, None)
+            return D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), self.tile_ids[slot].contiguous(), self.rects_dev, self.cfg, self.px)
 
-    def run_steps(n, timed):
-        cur = torch.cuda.current_stream()
-        s_fwd.wait_stream(cur)
-        s_post.wait_stream(cur)
-        res, pending, dones = (0, 0), None, [None, None]
-        for k in range(n):
-            if dones[k % 2] is not None:
-                s_fwd.wait_event(dones[k % 2])  # head buffer k%2 is free once step k-2 has been post-processed
-            f = launch_forward(k, timed)
+    def measure(scales, steps, warmup, pipeline=True):
+        """-> dict(dt, nrec, nmerged, fwd_ms per scale).  Two HIP streams, software-pipelined over steps: the forwards of step k+1 (whole
+        chip) are enqueued before the host starts the post-processing of step k (per-tile NMS / merge kernels: latency-bound, host-visible
+        counts).  Every step performs all of its work inside the timed region; nothing is reused between steps (heads double-buffered)."""
+        for sc in scales:
+            sc.ev = []
+
+        def launch_forward(k, timed):
+            with torch.cuda.stream(s_fwd):
+                heads = [sc.forward(k, timed) for sc in scales]
+                ready = torch.cuda.Event()
+                ready.record()
+            return heads, ready
+
+        def postprocess(heads, ready):
+            with torch.cuda.stream(s_post):
+                s_post.wait_event(ready)
+                sets, nrec = {}, 0
+                for sc, head in zip(scales, heads):
+                    rec = sc.records(head)
+                    if world > 1:
+                        rec = DD.all_gather_records(rec)
+                    nrec += len(rec)
+                    sets[sc.px] = D.records_to_detset(rec, sc.rects_dev, sc.cfg, sc.px)
+                fused = D.cross_scale_consensus_filter_device(sets) if len(scales) > 1 else sets[scales[0].px]  # Detect_OBB.py:290
+                merged, _ = D.merge_detections_device(fused, scales[0].cfg.iou_threshold)                    # :291
+                done = torch.cuda.Event()
+                done.record()
+            return nrec, len(merged), done
+
+        def run_steps(n, timed):
+            cur = torch.cuda.current_stream()
+            s_fwd.wait_stream(cur)
+            s_post.wait_stream(cur)
+            res, pending, dones = (0, 0), None, [None, None]
+            for k in range(n):
+                if dones[k % 2] is not None:
+                    s_fwd.wait_event(dones[k % 2])  # head buffer k%2 is free once step k-2 has been post-processed
+                f = launch_forward(k, timed)
+                if pending is not None:
+                    r = postprocess(*pending[1])
+                    res, dones[pending[0] % 2] = r[:2], r[2]
+                pending = (k, f)
+                if not pipeline:  # strictly sequential variant: finish step k before anything of step k+1 is enqueued
+                    r = postprocess(*pending[1])
+                    res, dones[k % 2] = r[:2], r[2]
+                    s_fwd.wait_event(r[2])
+                    pending = None
             if pending is not None:
                 r = postprocess(*pending[1])
-                res, dones[pending[0] % 2] = r[:2], r[2]
-                if not args.pipeline:
-                    s_fwd.wait_event(r[2])
-            pending = (k, f)
-            if not args.pipeline:  # strictly sequential variant: finish step k before anything of step k+1 is enqueued
-                r = postprocess(*pending[1])
-                res, dones[k % 2] = r[:2], r[2]
-                s_fwd.wait_event(r[2])
-                pending = None
-        if pending is not None:
-            r = postprocess(*pending[1])
-            res = r[:2]
-        cur.wait_stream(s_post)
-        cur.wait_stream(s_fwd)
-        return res
+                res = r[:2]
+            cur.wait_stream(s_post)
+            cur.wait_stream(s_fwd)
+            return res
 
-    nrec, nmerged = run_steps(args.warmup, False) if args.warmup else (0, 0)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nrec, nmerged = run_steps(args.steps, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev])) if fwd_ev else float("nan")
+        if warmup:
+            run_steps(warmup, False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrec, nmerged = run_steps(steps, True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return {"dt": dt, "nrec": nrec, "nmerged": nmerged, "fwd_ms": [float(np.mean([a.elapsed_time(b) for a, b in sc.ev])) for sc in scales]}
+
+    def roofline(precision, flop_per_step, fwd_ms):
+        ach = flop_per_step / (fwd_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision], "forward_ms": fwd_ms}
 
     def profiled_traffic():
         """HBM bytes of one forward from the committed rocprofv3 PMC passes of this build (FETCH_SIZE x2 + WRITE_SIZE, collected at 256
-        tiles, see tools/profile_all.sh), scaled to this step's tiles; None if the profile is not there."""
+        tiles, see tools/profile_all.sh), scaled to this step's tiles; (None, None) if no profile is there."""
         import re
-        try:
-            head = open(os.path.join(ROOT, "profiles", "r01_forward_hbm_traffic_b256.txt")).read(600)
-            m = re.search(r"-> ([0-9.]+) MB / tile", head)
-            return float(m.group(1)) * 1e6 * B if m else None
-        except OSError:
-            return None
+        for name in ("r02_forward_hbm_traffic_b256.txt", "r01_forward_hbm_traffic_b256.txt"):
+            try:
+                m = re.search(r"-> ([0-9.]+) MB / tile", open(os.path.join(ROOT, "profiles", name)).read(600))
+                if m:
+                    return float(m.group(1)) * 1e6 * B, "profiles/" + name
+            except OSError:
+                pass
+        return None, None
 
+    def single_scale(precision, channels):
+        model = YOLO(weights(channels, 0), imgsz=416, precision=precision)
+        rects = synthetic_rects(B * world)
+        tile_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
+        return model, [Scale(model, 416, B, rank, rects, tile_ids, channels)]
+
+    # ------------------------------------------------------------------ headline: configs[1] (or configs[3] with --channels 4)
+    hmodel, hscales = single_scale(args.precision, args.channels)
+    h = measure(hscales, args.steps, args.warmup, args.pipeline)
+    out = None
     if rank == 0:
-        tiles_per_s = world * B * args.steps / dt
-        achieved = B * (FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH) / (fwd_ms * 1e-3) / 1e12
+        flop = FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH
+        rf = roofline(args.precision, B * flop, h["fwd_ms"][0])
+        traffic, src = profiled_traffic() if (args.channels == 3 and args.precision != "f32") else (None, None)
+        rf.update({"traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per tile x tiles per step)") if src else None,
+                   "kernel": "k_conv_f32 family (whole forward)" if args.precision == "f32" else "k_conv_igemm family (whole forward)"})
         out = {
             "metric": "416px tiles/sec (whole node), YOLOv11n-OBB %dch" % args.channels,
-            "value": tiles_per_s, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.precision == "f16" else "bf16", "data": "synthetic",
+            "value": world * B * args.steps / h["dt"], "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": h["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("YOLOv11n-OBB 3ch 416x416 tiled inference, single-scale (BASELINE configs[1]): forward + decode + "
                                     "ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge") if args.channels == 3 else
                                    ("YOLOv11n-OBB 4ch (RGB + DT-edge) 416x416 tiled inference, single-scale (BASELINE configs[3] per GPU): build_multich + "
                                     "forward + decode + ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge"),
                        "tiles_per_gpu_per_step": B, "step_pipelining": bool(args.pipeline), "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
-                       "survivor_records_per_step": nrec, "final_detections": nmerged},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": profiled_traffic(), "traffic_source": "profiles/r01_forward_hbm_traffic_b256.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                         "passes of this build, bytes per tile x tiles per step)", "kernel": "k_conv_igemm family (whole forward)", "forward_ms": fwd_ms},
+                       "survivor_records_per_step": h["nrec"], "final_detections": h["nmerged"]},
+            "roofline": rf,
         }
-        if args.channels == 4:
-            out["roofline"]["traffic"] = None  # the committed PMC passes are of the 3-channel forward
+    del hscales
+    hmodel.close()
+
+    extras = not args.no_extras and world == 1
+    if extras and args.precision != "f32":
+        # ---------------------------------------------------------------- the same workload in the reference's own arithmetic (fp32)
+        m32, s32 = single_scale("f32", args.channels)
+        steps32 = max(3, args.steps // 2)
+        r = measure(s32, steps32, 2, args.pipeline)
+        if rank == 0:
+            flop = FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH
+            rf = roofline("f32", B * flop, r["fwd_ms"][0])
+            rf.update({"traffic": None, "kernel": "k_conv_f32 family (whole forward, v_mfma_f32_16x16x4_f32)"})
+            out["f32"] = {"value": B * steps32 / r["dt"], "unit": "tiles/s", "dtype": "f32", "steps": steps32, "warmup": 2, "ms_per_step": r["dt"] / steps32 * 1e3,
+                          "roofline": rf, "survivor_records_per_step": r["nrec"], "final_detections": r["nmerged"],
+                          "note": "fp32 weights / activations / accumulation end to end (obb_set_option precision 32): what Detect_OBB.py computes with half=False"}
+        del s32
+        m32.close()
+    if extras:
+        also = {}
+        # ---------------------------------------------------------------- BASELINE configs[2]: dual-scale (128 + 416) late fusion
+        # the virtual map of the B 416-px tiles (16 columns, stride 316) scanned at the 128-px scale as well (stride 98): both forwards,
+        # both per-tile paths, cross_scale_consensus_filter and the final merge inside every step (Detect_OBB.py:277-291)
+        cols, rows_ = 16, (B + 15) // 16
+        Wm, Hm = (cols - 1) * 316 + 416, (rows_ - 1) * 316 + 416
+        c128, r128 = len(range(0, Wm - 127, 98)), len(range(0, Hm - 127, 98))  # full 128-px tiles only
+        n128 = c128 * r128
+        rects128 = np.zeros((n128, 4), np.int32)
+        for t in range(n128):
+            x, y = (t % c128) * 98, (t // c128) * 98
+            rects128[t] = (x, y, x + 128, y + 128)
+        m128 = YOLO(weights(3, 1), imgsz=128, precision=args.precision)
+        m416 = YOLO(weights(3, 0), imgsz=416, precision=args.precision)
+        sc = [Scale(m128, 128, n128, 7, rects128, torch.arange(n128, dtype=torch.int32, device=dev)),
+              Scale(m416, 416, B, 0, synthetic_rects(B), torch.arange(B, dtype=torch.int32, device=dev))]
+        stepsd = max(3, args.steps // 2)
+        r = measure(sc, stepsd, 2, args.pipeline)
+        flopd = n128 * FLOP_PER_TILE_128 + B * FLOP_PER_TILE
+        also["dual_scale"] = {"workload": "BASELINE configs[2]: dual-scale (128 + 416) 3ch late fusion: per step %d 128-px tiles + %d 416-px tiles of one %dx%d virtual map -> "
+                                          "both forwards + decode + NMS + per-tile merges + cross_scale_consensus_filter + final merge" % (n128, B, Wm, Hm),
+                              "value": B * stepsd / r["dt"], "unit": "416px-tile map areas/s (each with its %.1f 128-px tiles)" % (n128 / B), "dtype": args.precision,
+                              "tiles_per_s_both_scales": (B + n128) * stepsd / r["dt"], "steps": stepsd, "ms_per_step": r["dt"] / stepsd * 1e3,
+                              "forward_ms": {"128": r["fwd_ms"][0], "416": r["fwd_ms"][1]},
+                              "roofline": roofline(args.precision, flopd, r["fwd_ms"][0] + r["fwd_ms"][1]),
+                              "survivor_records_per_step": r["nrec"], "final_detections": r["nmerged"]}
+        del sc
+        m128.close()
+        m416.close()
+        if args.channels == 3:
+            # ------------------------------------------------------------ BASELINE configs[3] per GPU: 4-channel (RGB + DT-edge) input
+            m4, s4 = single_scale(args.precision, 4)
+            r = measure(s4, stepsd, 2, args.pipeline)
+            also["ch4"] = {"workload": "BASELINE configs[3] per GPU: build_multich (DT-edge channel) + 4-channel forward + the same post-processing",
+                           "value": B * stepsd / r["dt"], "unit": "tiles/s", "dtype": args.precision, "steps": stepsd, "ms_per_step": r["dt"] / stepsd * 1e3,
+                           "roofline": roofline(args.precision, B * FLOP_PER_TILE_4CH, r["fwd_ms"][0])}
+            del s4
+            m4.close()
+        if rank == 0:
+            out["also"] = also
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.channels == 3:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

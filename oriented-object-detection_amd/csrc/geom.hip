@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ bo
                                                   int32_t nscales, double iou_partner, double cons_low, double cons_high,
                                                   uint8_t *__restrict__ state /* [total]: bit0 alive, bit1 visited */,
                                                   BoxMeta *__restrict__ meta, int32_t *__restrict__ out_idx,
-                                                  int32_t *__restrict__ n_out) {
+                                                  int32_t *__restrict__ n_out, const int32_t *__restrict__ only_if /* nullptr, or run only when *only_if != 0 */) {
+    if (only_if && *only_if == 0) return;
     __shared__ double r_conf[256], r_iou[256];
     __shared__ int32_t r_idx[256];
     __shared__ int32_t nout_s;
@@ -526,6 +527,155 @@ __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ bo
         }
     }
     if (tid == 0) *n_out = nout_s;
+}
+
+// ---- parallel form of cross_scale_consensus_filter (Detect_OBB.py:347-423)
+// The reference walks the detections in flat order (scales ascending, list order); an unvisited detection takes its best unvisited partner
+// from the other scales (same class, polygon IoU >= 0.40; best = higher confidence, then higher IoU, then first in pool order) and both
+// become visited.  That is a greedy matching on a SPARSE graph: (1) the candidate edges are found by the whole chip (k_cons_edges: every
+// cross-scale same-class pair, envelope test first, exact IoU for the few that pass); (2) the greedy order is then resolved in rounds by one
+// workgroup (k_cons_resolve): a detection decides as soon as every earlier detection within two hops (a neighbour, or a rival for one of
+// its neighbours) has decided -- exactly the information the sequential walk would have had at its turn -- so each round decides many
+// independent clusters at once and the result is identical to the walk.  Adjacency lists are fixed-capacity (kConsK per detection); if one
+// overflows, the single-workgroup walk (k_consensus) runs instead.
+static constexpr int kConsK = 32;
+
+__global__ __launch_bounds__(256) void k_cons_prep(const double *__restrict__ boxes, const double *__restrict__ conf, const int64_t *__restrict__ off,
+                                                  int32_t nscales, double cons_low, uint8_t *__restrict__ state, uint8_t *__restrict__ scale_id,
+                                                  BoxMeta *__restrict__ meta, int32_t *__restrict__ deg, int32_t *__restrict__ flags) {
+    const int64_t total = off[nscales];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { flags[0] = 0; flags[1] = 0; }
+    if (i >= total) return;
+    state[i] = (conf[i] >= cons_low) ? 1 : 0;  // :361-364
+    int sc = 0;
+    while (sc + 1 < nscales && i >= off[sc + 1]) ++sc;
+    scale_id[i] = (uint8_t)sc;
+    deg[i] = 0;
+    P2 p[4];
+    for (int k = 0; k < 4; ++k) { p[k].x = boxes[i * 8 + 2 * k]; p[k].y = boxes[i * 8 + 2 * k + 1]; }
+    BoxMeta m;
+    if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+    else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
+    meta[i] = m;
+}
+
+// grid (ceil(total / 256), ceil(total / 64)): thread = one j, block row = 64 i's held in LDS; pairs i < j of different scales only
+__global__ __launch_bounds__(256) void k_cons_edges(const double *__restrict__ boxes, const int32_t *__restrict__ cls, const uint8_t *__restrict__ state,
+                                                   const uint8_t *__restrict__ scale_id, const BoxMeta *__restrict__ meta, int64_t total, double iou_thr,
+                                                   int32_t *__restrict__ adj_idx, double *__restrict__ adj_iou, int32_t *__restrict__ deg,
+                                                   int32_t *__restrict__ flags) {
+    __shared__ BoxMeta sm[64];
+    __shared__ int32_t sc[64];
+    __shared__ int16_t ss[64];  // scale id, or -1 for a detection that takes no part (below CONS_LOW)
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 256;
+    if (j0 + 255 <= i0) return;  // no pair with i < j in this block
+    if (threadIdx.x < 64) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool ok = i < total && state[i] == 1;
+        ss[threadIdx.x] = ok ? (int16_t)scale_id[i] : (int16_t)-1;
+        sc[threadIdx.x] = ok ? cls[i] : 0;
+        if (i < total) sm[threadIdx.x] = meta[i];
+    }
+    __syncthreads();
+    const int64_t j = j0 + threadIdx.x;
+    if (j >= total || state[j] != 1) return;
+    const BoxMeta mj = meta[j];
+    const int cj = cls[j], sj = scale_id[j];
+    for (int r = 0; r < 64; ++r) {
+        const int64_t i = i0 + r;
+        if (i >= j) break;
+        if (ss[r] < 0 || ss[r] == sj || sc[r] != cj || !meta_overlap(sm[r], mj)) continue;
+        P2 p[4], q[4];
+        for (int k = 0; k < 4; ++k) {
+            p[k].x = boxes[i * 8 + 2 * k]; p[k].y = boxes[i * 8 + 2 * k + 1];
+            q[k].x = boxes[j * 8 + 2 * k]; q[k].y = boxes[j * 8 + 2 * k + 1];
+        }
+        // the walk evaluates compute_polygon_iou(d, p) with d = the detection being processed: the earlier one (i) in every pair that
+        // can matter (a later detection never looks back at a visited one), so (i, j) is the argument order to reproduce bit for bit
+        const double iou = poly_iou_core(p, q);
+        if (!(iou >= iou_thr)) continue;
+        const int a = atomicAdd(&deg[i], 1), b = atomicAdd(&deg[j], 1);
+        if (a < kConsK) { adj_idx[i * kConsK + a] = (int32_t)j; adj_iou[i * kConsK + a] = iou; } else flags[0] = 1;
+        if (b < kConsK) { adj_idx[j * kConsK + b] = (int32_t)i; adj_iou[j * kConsK + b] = iou; } else flags[0] = 1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cons_resolve(const double *__restrict__ conf, int64_t total, double cons_high, uint8_t *__restrict__ state,
+                                                      const int32_t *__restrict__ adj_idx, const double *__restrict__ adj_iou, const int32_t *__restrict__ deg,
+                                                      int32_t *__restrict__ decision, int32_t *__restrict__ emit, int32_t *__restrict__ flags,
+                                                      int32_t *__restrict__ out_idx, int32_t *__restrict__ n_out) {
+    if (flags[0]) return;  // adjacency overflow: k_consensus (launched behind this kernel) does the walk
+    __shared__ int s_any, s_base, s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t i = tid; i < total; i += 1024) {
+        int e = -1;
+        if (state[i] == 1 && deg[i] == 0) { e = conf[i] >= cons_high ? (int32_t)i : -1; state[i] = 3; }  // no candidate partner at all: :406-410
+        emit[i] = e;
+    }
+    __syncthreads();
+    for (int64_t round = 0; round <= total; ++round) {
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < total; i += 1024) {
+            int dec = -2;  // not this round
+            if (state[i] == 1) {
+                const int di = deg[i];
+                bool ready = true;
+                for (int a = 0; a < di && ready; ++a) {
+                    const int j = adj_idx[i * kConsK + a];
+                    if (state[j] != 1) continue;  // visited: no longer a candidate, and it blocks nothing
+                    if (j < i) { ready = false; break; }  // j is walked before i and may or may not take i
+                    const int dj = deg[j];
+                    for (int b = 0; b < dj; ++b) {
+                        const int k = adj_idx[j * kConsK + b];
+                        if (k < i && state[k] == 1) { ready = false; break; }  // an earlier rival for j has not decided yet
+                    }
+                }
+                if (ready) {
+                    double bc = -1.0, bi = 0.0;
+                    int bj = -1;
+                    for (int a = 0; a < di; ++a) {
+                        const int j = adj_idx[i * kConsK + a];
+                        if (state[j] != 1) continue;
+                        const double cp = conf[j], iou = adj_iou[i * kConsK + a];
+                        // :397-399 with the pool scanned in ascending position: higher confidence, then higher IoU, then the earlier one
+                        if (bj < 0 || cp > bc || (cp == bc && (iou > bi || (iou == bi && j < bj)))) { bc = cp; bi = iou; bj = j; }
+                    }
+                    dec = bj;
+                } else s_any = 1;
+            }
+            decision[i] = dec;
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < total; i += 1024) {
+            const int dec = decision[i];
+            if (dec == -2) continue;
+            if (dec < 0) emit[i] = conf[i] >= cons_high ? (int32_t)i : -1;  // :406-410
+            else { emit[i] = conf[i] >= conf[dec] ? (int32_t)i : dec; state[dec] = 3; }  // :412-421
+            state[i] = 3;
+        }
+        __syncthreads();
+        if (!s_any) break;
+        __syncthreads();
+    }
+    // kept list = the emitting detections in walk order: ordered compaction of emit[]
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < total; c0 += 1024) {
+        const int64_t i = c0 + tid;
+        const int e = i < total ? emit[i] : -1;
+        const unsigned long long bal = __ballot(e >= 0);
+        if (lane == 0) s_wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        if (e >= 0) out_idx[s_base + before + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_wsum[w]; s_base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { *n_out = s_base; flags[1] = 1; }
 }
 
 // ------------------------------------------------------------------------------------------------ detect_symbols per-detection body
@@ -765,12 +915,35 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
     if (total == 0) { OBB_HIP(ctx, hipMemsetAsync(n_out, 0, sizeof(int32_t), st)); return OBB_OK; }
     OBB_REQUIRE(ctx, boxes && cls && conf && out_idx, "obb_consensus: NULL buffer");
     int64_t *off = (int64_t *)ctx->workspace(WS_GEOM_D, 256);
-    uint8_t *state = (uint8_t *)ctx->workspace(WS_GEOM_C, (size_t)total);
+    uint8_t *state = (uint8_t *)ctx->workspace(WS_GEOM_C, (size_t)total * 2 + 256);
     BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)total);
     if (!off || !state || !meta) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
     OBB_HIP(ctx, hipMemcpyAsync(off, off_host, sizeof(int64_t) * (nscales + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner,
-                       cons_low, cons_high, state, meta, out_idx, n_out);
+    if (nscales == 1 || total < 512) {  // passthrough (:357-358), or small enough for the single-workgroup walk
+        hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner,
+                           cons_low, cons_high, state, meta, out_idx, n_out, (const int32_t *)nullptr);
+        OBB_LAUNCH_CHECK(ctx);
+        return OBB_OK;
+    }
+    OBB_REQUIRE(ctx, total < (1ll << 31) && cdiv(total, 64) <= 65535, "obb_consensus: %lld detections exceed the grid limit", (long long)total);
+    uint8_t *scale_id = state + (((size_t)total + 127) & ~(size_t)127);
+    int32_t *adj_idx = (int32_t *)ctx->workspace(WS_NMS_B, sizeof(int32_t) * (size_t)total * kConsK);
+    double *adj_iou = (double *)ctx->workspace(WS_NMS_C, sizeof(double) * (size_t)total * kConsK);
+    int32_t *ibuf = (int32_t *)ctx->workspace(WS_GEOM_A, sizeof(int32_t) * ((size_t)total * 3 + 64));  // deg | decision | emit | flags
+    if (!adj_idx || !adj_iou || !ibuf) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
+    int32_t *deg = ibuf, *decision = ibuf + total, *emit = ibuf + 2 * total, *flags = ibuf + 3 * total;
+    hipLaunchKernelGGL(k_cons_prep, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, boxes, conf, (const int64_t *)off, nscales, cons_low, state, scale_id, meta,
+                       deg, flags);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_cons_edges, dim3((unsigned)cdiv(total, 256), (unsigned)cdiv(total, 64)), dim3(256), 0, st, boxes, cls, (const uint8_t *)state,
+                       (const uint8_t *)scale_id, (const BoxMeta *)meta, total, iou_partner, adj_idx, adj_iou, deg, flags);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_cons_resolve, dim3(1), dim3(1024), 0, st, conf, total, cons_high, state, (const int32_t *)adj_idx, (const double *)adj_iou,
+                       (const int32_t *)deg, decision, emit, flags, out_idx, n_out);
+    OBB_LAUNCH_CHECK(ctx);
+    // a detection with more than kConsK candidate partners (flags[0]): the walk itself, on untouched state (it re-derives state and meta)
+    hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner, cons_low, cons_high, state,
+                       meta, out_idx, n_out, (const int32_t *)flags);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

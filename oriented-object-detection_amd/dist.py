@@ -2,9 +2,11 @@
 
 Tiles are independent through forward / decode / Fast-NMS / border filter / per-tile merge (Detect_OBB.py:216-264 has
 no cross-tile state), so the tile list is sharded across ranks with no data-path collective.  Only the fusion steps
-(:290-291) need every detection of an image: survivors are exchanged once per image as fixed 48-byte records
-(all-gather of counts, then one all-gather of padded record buffers -- KB-scale, latency-bound, a single step), after
-which every rank holds the identical, tile-ordered record list and runs the fusion replicated.
+(:290-291) need every detection of an image: survivors are exchanged once per image as fixed 48-byte records in ONE
+fixed-capacity all-gather (row 0 of every rank's buffer carries its count; KB- to MB-scale, latency-bound, a single
+step, one host read), after which every rank holds the identical, tile-ordered record list and runs the fusion replicated.
+RCCL itself has not been executed yet (no multi-GPU box was available to the builder): the exchange is covered by 2-rank gloo
+tests on CPU and a 2-rank gloo rehearsal on one MI355X.
 """
 import torch
 import torch.distributed as dist
@@ -20,9 +22,12 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_records(rec, group=None):
-    """Variable-length all-gather of TileRecords; result is ordered by (rank, local order) == tile order for
-    contiguous shards."""
+def all_gather_records(rec, group=None, capacity=None):
+    """Variable-length all-gather of TileRecords in ONE collective: every rank contributes a fixed-capacity int32 [capacity + 1, 12]
+    buffer whose row 0 carries its record count; the `world` counts are then read with one host transfer and the valid rows sliced.
+    Result is ordered by (rank, local order) == tile order for contiguous shards.  `capacity` (records per rank) defaults to the next
+    power of two above this rank's count, agreed through the same collective: a rank whose count exceeds the agreed capacity triggers
+    one second, larger exchange (rare: survivors are a few per tile), so nothing is ever truncated."""
     world = dist.get_world_size(group)
     if world == 1:
         return rec
@@ -31,18 +36,31 @@ def all_gather_records(rec, group=None):
     # through host memory.
     xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
     buf = rec.pack().to(xdev)
-    n = torch.tensor([buf.shape[0]], dtype=torch.int64, device=xdev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts)
-    if mx == 0:
-        return rec
-    padded = torch.zeros((mx, 12), dtype=torch.int32, device=xdev)
-    padded[: buf.shape[0]] = buf
-    outs = [torch.zeros((mx, 12), dtype=torch.int32, device=xdev) for _ in range(world)]
-    dist.all_gather(outs, padded, group=group)
-    return TileRecords.unpack(torch.cat([o[:c] for o, c in zip(outs, counts)], 0).contiguous().to(dev))
+    n = buf.shape[0]
+
+    def exchange(cap):
+        send = torch.zeros((cap + 1, 12), dtype=torch.int32, device=xdev)
+        send[0, 0] = n
+        m = min(n, cap)
+        send[1:1 + m] = buf[:m]
+        recv = torch.empty(world * (cap + 1) * 12, dtype=torch.int32, device=xdev)
+        dist.all_gather_into_tensor(recv, send.view(-1), group=group)
+        recv = recv.view(world, cap + 1, 12)
+        return recv, recv[:, 0, 0].tolist()  # the one host read of this step
+
+    cap = int(capacity) if capacity else _DEFAULT_CAPACITY.get("cap", 1024)
+    recv, counts = exchange(cap)
+    if max(counts) > cap:  # some rank did not fit: every rank sees the same counts, so every rank takes this branch
+        cap = 1 << (max(counts) - 1).bit_length()
+        _DEFAULT_CAPACITY["cap"] = max(_DEFAULT_CAPACITY.get("cap", 1024), cap)  # sticky: the next steps start large enough
+        recv, counts = exchange(cap)
+    if sum(counts) == 0:
+        return TileRecords.empty(dev)
+    rows = torch.cat([recv[r, 1:1 + c] for r, c in enumerate(counts) if c], 0)
+    return TileRecords.unpack(rows.contiguous().to(dev))
+
+
+_DEFAULT_CAPACITY = {}
 
 
 def detect_symbols_distributed(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256, group=None):

@@ -34,6 +34,11 @@ WORKER = textwrap.dedent('''
     e = DD.all_gather_records(mine if rank == 0 else D.TileRecords.empty("cpu"))
     ok = ok and len(e) == int((full.tile < DD.shard_bounds(ntiles, 0, world)[1]).sum())
     ok = ok and len(DD.all_gather_records(D.TileRecords.empty("cpu"))) == 0
+    # a capacity smaller than one rank's count: the second, larger exchange must deliver everything, and stick for the next call
+    got2 = DD.all_gather_records(mine, capacity=4)
+    ok = ok and torch.equal(got2.tile, full.tile) and torch.equal(got2.pts, full.pts) and torch.equal(got2.conf, full.conf)
+    got3 = DD.all_gather_records(mine)
+    ok = ok and torch.equal(got3.tile, full.tile) and torch.equal(got3.cls, full.cls)
     flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     sys.exit(0 if int(flag.item()) == 1 else 3)

@@ -202,6 +202,39 @@ def test_detect_symbols_body_matches_reference(ops):
         assert np.max(np.abs(got[:, 10] - exp[:, 10]), initial=0.0) <= 1e-9  # atan2 ulp differences only
 
 
+def _cross_scale_sets(seed, sizes, extent, jitter=5.0):
+    """detections of several scales over one map: every scale sees (a random subset of) the same objects, slightly displaced"""
+    rng = np.random.default_rng(seed)
+    base_b, base_c, _, base_x = synth.make_dets(seed, max(sizes), extent=extent, dup_frac=0.2)
+    bs, cs, ss = [], [], []
+    for k, n in enumerate(sizes):
+        pick = rng.permutation(len(base_c))[:n]
+        x = base_x[pick].copy()
+        x[:, 0] += rng.normal(0, jitter, n); x[:, 1] += rng.normal(0, jitter, n)
+        x[:, 2:4] *= rng.uniform(0.9, 1.1, (n, 2))
+        loc = synth.xywhr_to_corners_f32(x.astype(np.float32)).astype(np.float64)
+        off = base_b[pick][:, :2] - synth.xywhr_to_corners_f32(base_x[pick]).astype(np.float64)[:, :2]   # the tile offset of the base box
+        loc[:, 0::2] += np.round(off[:, 0:1]); loc[:, 1::2] += np.round(off[:, 1:2])
+        bs.append(loc); cs.append(base_c[pick].astype(np.int32))
+        conf = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        conf[rng.integers(0, n, max(2, n // 10))] = conf[0]                    # exact confidence ties
+        ss.append(conf.astype(np.float64))
+    return np.concatenate(bs), np.concatenate(cs), np.concatenate(ss), [0] + list(np.cumsum(sizes))
+
+
+@pytest.mark.parametrize("sizes,extent", [((3000, 2200), 3000.0), ((900, 700, 800), 1500.0), ((20000, 6000), 9000.0), ((600, 40), 60.0)])
+def test_consensus_parallel_form_matches_the_walk(ops, sizes, extent):
+    """above 512 detections the candidate edges are built by the whole chip and the greedy order is resolved in dependency rounds;
+    kept indices and their order must equal the sequential walk of Detect_OBB.py:373-421 (C oracle), for 2 and 3 scales, with confidence
+    ties, and -- last case: 600 + 40 boxes piled onto one spot -- when an adjacency list overflows and the walk kernel takes over"""
+    b, c, s, off = _cross_scale_sets(17 + len(sizes), sizes, extent)
+    exp = og.consensus_arrays(b, c, s, off)
+    idx, nout = ops.consensus(dev(b, torch.float64), dev(c, torch.int32), dev(s, torch.float64), off)
+    got = idx.cpu().numpy()[:int(nout.item())]
+    assert len(exp) > 10
+    assert np.array_equal(got, exp), (len(got), len(exp))
+
+
 @pytest.mark.parametrize("name", ["Test1", "Test2"])
 def test_xlsx_goldens_are_fixed_points(ops, name):
     names, boxes, conf, angle = load_xlsx_csv(name)

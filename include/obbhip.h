@@ -155,6 +155,11 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
  * out float[B*max_det*7] rows (x, y, w, h, conf, cls, theta) in score order; count int32[B]. */
 int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres,
                    int32_t max_det, float *out, int32_t *count, obb_stream_t s);
+/* The same function in its full form (decode every anchor, then NMS sized for all of them): an independent implementation kept for the
+ * parity tests, which require obb_decode_nms (candidate-first: conf filter on the class logits, decode + NMS of the survivors only) to
+ * return the same rows bit for bit. */
+int obb_decode_nms_full(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres,
+                        int32_t max_det, float *out, int32_t *count, obb_stream_t s);
 /* Pieces of the above for parity tests: decoded predictions float[B*A*(4+nc+1)] (x,y,w,h, cls scores, theta). */
 int obb_decode(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float *pred, obb_stream_t s);
 /* ProbIoU Fast-NMS on one candidate list: boxes float[n*5] (x,y,w,h,theta; class offset applied), scores float[n]. */

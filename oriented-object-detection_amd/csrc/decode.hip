@@ -7,6 +7,8 @@
 //   k_gather_tiles / k_letterbox   the tiler's crop (Detect_OBB.py:218-220) and LetterBox(auto=True) preprocess
 // SURVEY.md Appendix A2/A4/A6.  These are HBM/latency-bound kernels: one workgroup per tile, candidates kept in
 // anchor order by ballot/prefix-sum compaction so that ties sort exactly like a stable argsort.
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "ctx.h"
@@ -21,13 +23,9 @@ static constexpr float kMaxWh = 7680.0f;
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------- decode
-__global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, int B, int A, int nc, int h, int w,
-                                               float *__restrict__ pred) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * A) return;
-    int a = (int)(i % A);
-    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4, np = 4 + nc + 1;  // head rows are padded to a multiple of 4 floats
-    const float *hp = head + i * no;
+// box (x, y, w, h in letterboxed-input pixels) and angle of anchor `a` from its head row: DFL softmax-expectation, dist2rbox, angle
+// (one definition for the full decode and for the candidate-first path: identical arithmetic by construction)
+__device__ __forceinline__ void decode_anchor(const float *__restrict__ hp, int a, int nc, int h, int w, float &ox, float &oy, float &ow, float &oh, float &oang) {
     // anchor of this row: levels P3, P4, P5 concatenated, row-major inside a level, centres at +0.5
     int n8 = (h / 8) * (w / 8), n16 = (h / 16) * (w / 16);
     int stride, lw, la;
@@ -55,11 +53,26 @@ __global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, 
     float xf = (d[2] - d[0]) / 2.0f, yf = (d[3] - d[1]) / 2.0f;
     float x = xf * c - yf * s, y = xf * s + yf * c;
     float fs = (float)stride;
+    ox = (x + ax) * fs;
+    oy = (y + ay) * fs;
+    ow = (d[0] + d[2]) * fs;
+    oh = (d[1] + d[3]) * fs;
+    oang = ang;
+}
+
+// full decode of every anchor (parity tap obb_decode, and the fall-back of tiles with more candidates than the fast path holds:
+// `only_flagged` != nullptr restricts the work to tiles whose count is -1)
+__global__ __launch_bounds__(256) void k_decode(const float *__restrict__ head, int B, int A, int nc, int h, int w,
+                                               float *__restrict__ pred, const int32_t *__restrict__ only_flagged) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * A) return;
+    if (only_flagged && only_flagged[i / A] != -1) return;
+    int a = (int)(i % A);
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4, np = 4 + nc + 1;  // head rows are padded to a multiple of 4 floats
+    const float *hp = head + i * no;
     float *pp = pred + i * np;
-    pp[0] = (x + ax) * fs;
-    pp[1] = (y + ay) * fs;
-    pp[2] = (d[0] + d[2]) * fs;
-    pp[3] = (d[1] + d[3]) * fs;
+    float ang;
+    decode_anchor(hp, a, nc, h, w, pp[0], pp[1], pp[2], pp[3], ang);
     for (int k = 0; k < nc; ++k) pp[4 + k] = sigmoid_f(hp[4 * kRegMaxD + k]);
     pp[4 + nc] = ang;
 }
@@ -117,10 +130,7 @@ __device__ __forceinline__ int probiou_fast_decision(const RBox &p, const RBox &
     return 0;
 }
 
-static bool nms_exact_only() { static const bool v = getenv("OBB_NMS_EXACT") && atoi(getenv("OBB_NMS_EXACT")); return v; }
-
 static float probiou_bdmax(float thr) {
-    if (nms_exact_only()) return -1.0f;
     double s = 1.0 + 1e-7 - (1.0 - (double)thr) * (1.0 - (double)thr);
     if (!(thr > 1e-3f) || s <= 0.0 || s >= 1.0) return -1.0f;  // disables the fast path
     return (float)(-log(s));
@@ -136,7 +146,6 @@ __device__ __forceinline__ bool far_apart(const RBox &p, const RBox &q, float kq
 }
 
 static float far_apart_factor(float thr) {
-    if (getenv("OBB_NMS_EXACT") && atoi(getenv("OBB_NMS_EXACT"))) return INFINITY;
     double s = 1.0 + 1e-7 - (1.0 - (double)thr) * (1.0 - (double)thr);
     if (!(thr > 1e-3f) || s <= 0.0 || s >= 1.0) return INFINITY;  // never reject
     return (float)(4.0 * -log(s) * 1.05);
@@ -173,10 +182,11 @@ struct NmsScratch {  // per tile, capacity A rows each
 template <bool LDS_RESIDENT>
 __global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pred, int A, int nc, float conf_thres, float iou_thres,
                                                   int max_det, int max_nms, float kq, float bdmax, NmsScratch S, float *__restrict__ out,
-                                                  int32_t *__restrict__ count) {
+                                                  int32_t *__restrict__ count, int only_flagged) {
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
     __shared__ int wave_tot[16];
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    if (only_flagged && count[b] != -1) return;  // fall-back launch: only the tiles the candidate-first kernel handed over
     const int np = 4 + nc + 1;
     const float *pb = pred + (int64_t)b * A * np;
     RBox *rb; float *cscore; int32_t *cand, *order; uint8_t *ccls, *scls, *keep;
@@ -281,6 +291,280 @@ __global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pre
         }
     }
     if (tid == 0) count[b] = m < max_det ? m : max_det;
+}
+
+// Candidate-first form of decode + non_max_suppression(rotated=True) (obb_decode_nms).  A 416-px tile has 3549 anchors and, at conf
+// 0.25, about a dozen candidates: decoding every anchor and sizing the NMS for all of them spends its time on rows that are dropped.
+//
+// k_cand_nms: one 256-thread workgroup per tile, 18 KB of LDS (several per CU, next to the convolution kernels of the next forward):
+//   1. candidate test on the class logits only (48 of the 320 bytes of a head row, three 16-B loads): an anchor whose largest logit
+//      is below logit(conf) - guard cannot pass; the others get the exact sigmoid of every class (first maximum, conf > thr) exactly
+//      like the full decode; survivors are compacted in anchor order (stable ties) into LDS and into the tile's global scratch rows;
+//   2. DFL / dist2rbox / angle for the survivors only (decode_anchor: the code k_decode runs);
+//   3. stable rank sort, covariance terms, Fast-NMS and the max_det cut on LDS arrays of kCandCap rows.
+// A tile with more than kCandCap candidates (a saturated tile, or metrics mode at conf 0.001) is appended to a device-side list and
+// finished by three kernels that spread ONE tile over many workgroups (k_heavy_sort / k_heavy_nms / k_heavy_out): its O(n^2) rank sort
+// and pair loop are row-parallel, so the slowest tile no longer sets the time of the whole call.  Results are identical to the full
+// decode + k_nms_tile path (kept as the parity reference in tests): same candidates, same arithmetic, same order.
+static constexpr int kCandCap = 256;
+static constexpr int kHeavySlots = 64;   // flagged tiles are walked by this many block columns (grid-stride)
+
+struct HeavyScratch {  // per tile, stride AS rows (AS = A rounded up to 4)
+    int32_t *cand;     // anchor of candidate k (anchor order)
+    float *cscore;     // its confidence
+    uint8_t *ccls;     // its class
+    RBox *rb;          // sorted order: covariance terms (class offset applied)
+    float *sbox;       // sorted order: [5] x, y, w, h, theta
+    float *sscore;     // sorted order
+    uint8_t *scls, *keep;  // sorted order
+    int32_t *ncand;    // [B] candidates of a flagged tile
+    int32_t *flist;    // [B] flagged tiles
+    int32_t *nflag;    // [1]
+};
+
+// class scores of one anchor: three 16-byte loads instead of nc scalar ones (rows are padded to a multiple of 4 floats, columns past nc
+// are masked); returns the exact (best sigmoid, first maximum) pair, or best = -inf when the largest logit is below the gate
+__device__ __forceinline__ void class_best(const float *__restrict__ cp, int nc, float logit_gate, float &best, int &bj) {
+    float lg[16];
+    float mx = -INFINITY;
+    const int n4 = (nc + 3) >> 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < n4) {
+            const float4 v = *reinterpret_cast<const float4 *>(cp + 4 * q);
+            lg[4 * q] = v.x; lg[4 * q + 1] = v.y; lg[4 * q + 2] = v.z; lg[4 * q + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < nc) mx = fmaxf(mx, lg[j]);
+    best = -INFINITY; bj = 0;
+    if (mx > logit_gate) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < nc) { const float v = sigmoid_f(lg[j]); if (v > best) { best = v; bj = j; } }
+    }
+}
+
+template <bool WIDE /* nc <= 16: vector loads */>
+__global__ __launch_bounds__(256) void k_cand_nms(const float *__restrict__ head, int A, int nc, int h, int w, float conf_thres, float logit_gate,
+                                                 float iou_thres, int max_det, float kq, float bdmax, HeavyScratch S, float *__restrict__ out,
+                                                 int32_t *__restrict__ count) {
+    __shared__ int wave_tot[16];
+    __shared__ __attribute__((aligned(16))) RBox rb[kCandCap];
+    __shared__ float cbox[kCandCap][5];
+    __shared__ float cscore[kCandCap];
+    __shared__ int32_t cand[kCandCap], order[kCandCap];
+    __shared__ uint8_t ccls[kCandCap], scls[kCandCap], keep[kCandCap];
+    constexpr int NT = 256;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4;
+    const float *hb = head + (int64_t)b * A * no;
+    const int64_t AS = (A + 3) & ~3;
+    int32_t *gcand = S.cand + (int64_t)b * AS;
+    float *gscore = S.cscore + (int64_t)b * AS;
+    uint8_t *gcls = S.ccls + (int64_t)b * AS;
+
+    // 1. candidates in anchor order
+    int n = 0;
+    for (int a0 = 0; a0 < A; a0 += NT) {
+        const int a = a0 + tid;
+        float best = -INFINITY;
+        int bj = 0;
+        if (a < A) {
+            const float *cp = hb + (int64_t)a * no + 4 * kRegMaxD;
+            if constexpr (WIDE) class_best(cp, nc, logit_gate, best, bj);
+            else {
+                float mx = -INFINITY;
+                for (int j = 0; j < nc; ++j) mx = fmaxf(mx, cp[j]);
+                if (mx > logit_gate)
+                    for (int j = 0; j < nc; ++j) { const float v = sigmoid_f(cp[j]); if (v > best) { best = v; bj = j; } }
+            }
+        }
+        const bool flag = (a < A) && (best > conf_thres);
+        const int slot = ordered_slot(flag, wave_tot, n);
+        if (flag) {
+            gcand[slot] = a; gscore[slot] = best; gcls[slot] = (uint8_t)bj;  // (the copy a tile above kCandCap is finished from)
+            if (slot < kCandCap) { cand[slot] = a; cscore[slot] = best; ccls[slot] = (uint8_t)bj; }
+        }
+    }
+    __syncthreads();
+    if (n == 0) { if (tid == 0) count[b] = 0; return; }
+    if (n > kCandCap) {  // handed to the row-parallel kernels
+        if (tid == 0) { S.ncand[b] = n; S.flist[atomicAdd(S.nflag, 1)] = b; count[b] = 0; }
+        return;
+    }
+
+    // 2. decode the candidates
+    for (int k = tid; k < n; k += NT) {
+        const int a = cand[k];
+        decode_anchor(hb + (int64_t)a * no, a, nc, h, w, cbox[k][0], cbox[k][1], cbox[k][2], cbox[k][3], cbox[k][4]);
+    }
+    // 3a. stable descending rank sort by confidence
+    for (int i = tid; i < n; i += NT) {
+        const float si = cscore[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const float sj = cscore[j]; rank += (sj > si) | ((sj == si) & (j < i)); }
+        order[rank] = i;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += NT) {
+        const int k = order[r];
+        const float c = (float)ccls[k] * kMaxWh;  // class offset: boxes of different classes never overlap
+        rb[r] = make_rbox(cbox[k][0] + c, cbox[k][1] + c, cbox[k][2], cbox[k][3], cbox[k][4]);
+        scls[r] = ccls[k];
+    }
+    __syncthreads();
+    // 3b. Fast-NMS: keep r iff no i < r with probiou(i, r) >= thr (suppressed boxes still suppress); one wave per row
+    const bool skip_other_cls = iou_thres > 1e-3f;
+    {
+        const int lane = tid & 63, wave = tid >> 6, nwave = NT >> 6;
+        for (int r = wave; r < n; r += nwave) {
+            const RBox q = rb[r];
+            const uint8_t cq = scls[r];
+            bool hit = false;
+            for (int i0 = 0; i0 < r; i0 += 64) {
+                const int i = i0 + lane;
+                bool hh = false;
+                if (i < r && !(skip_other_cls && scls[i] != cq)) {
+                    const RBox p = rb[i];
+                    if (!far_apart(p, q, kq)) {
+                        const int dec = bdmax > 0.0f ? probiou_fast_decision(p, q, bdmax) : 0;
+                        hh = dec > 0 || (dec == 0 && probiou(p, q) >= iou_thres);
+                    }
+                }
+                if (__ballot(hh)) { hit = true; break; }
+            }
+            if (lane == 0) keep[r] = (uint8_t)!hit;
+        }
+    }
+    __syncthreads();
+    // 4. first max_det survivors in score order -> rows (x, y, w, h, conf, cls, theta)
+    int m = 0;
+    float *ob = out + (int64_t)b * max_det * 7;
+    for (int r0 = 0; r0 < n && m < max_det; r0 += NT) {
+        const int r = r0 + tid;
+        const bool flag = (r < n) && keep[r];
+        const int slot = ordered_slot(flag, wave_tot, m);
+        if (flag && slot < max_det) {
+            const int k = order[r];
+            float *o = ob + (int64_t)slot * 7;
+            o[0] = cbox[k][0]; o[1] = cbox[k][1]; o[2] = cbox[k][2]; o[3] = cbox[k][3];
+            o[4] = cscore[k]; o[5] = (float)ccls[k]; o[6] = cbox[k][4];
+        }
+    }
+    if (tid == 0) count[b] = m < max_det ? m : max_det;
+}
+
+// ---- tiles above kCandCap candidates, one tile spread over many workgroups.  grid (kHeavySlots, chunks): block column s walks the flagged
+//      tiles s, s + kHeavySlots, ...
+// rank of candidate i among the tile's n scores (stable, descending) + its decoded box -> sorted arrays
+__global__ __launch_bounds__(256) void k_heavy_sort(const float *__restrict__ head, int A, int nc, int h, int w, int max_nms, HeavyScratch S) {
+    __shared__ __attribute__((aligned(16))) float sc[1024];
+    const int tid = threadIdx.x;
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4;
+    const int64_t AS = (A + 3) & ~3;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const int n = S.ncand[b];
+        const float *gscore = S.cscore + (int64_t)b * AS;
+        for (int i0 = blockIdx.y * 256; i0 < n; i0 += gridDim.y * 256) {  // (uniform per block: the barriers below are safe)
+            const int i = i0 + tid;
+            const float si = i < n ? gscore[i] : 0.f;
+            int rank = 0;
+            for (int j0 = 0; j0 < n; j0 += 1024) {  // 1024 scores per LDS chunk (padding -inf never outranks anything), four compares per 16-B read
+                __syncthreads();
+                for (int q = tid; q < 1024; q += 256) sc[q] = j0 + q < n ? gscore[j0 + q] : -INFINITY;
+                __syncthreads();
+                const int lim = min(1024, (n - j0 + 3) & ~3);
+                for (int j = 0; j < lim; j += 4) {
+                    const float4 sj = *reinterpret_cast<const float4 *>(sc + j);
+                    const int jj = j0 + j;
+                    rank += (sj.x > si) | ((sj.x == si) & (jj < i));
+                    rank += (sj.y > si) | ((sj.y == si) & (jj + 1 < i));
+                    rank += (sj.z > si) | ((sj.z == si) & (jj + 2 < i));
+                    rank += (sj.w > si) | ((sj.w == si) & (jj + 3 < i));
+                }
+            }
+            if (i < n && rank < max_nms) {  // n > max_nms keeps the top max_nms
+                const int a = S.cand[(int64_t)b * AS + i];
+                const int cls = S.ccls[(int64_t)b * AS + i];
+                float x, y, ww, hh, t;
+                decode_anchor(head + ((int64_t)b * A + a) * no, a, nc, h, w, x, y, ww, hh, t);
+                const int64_t r = (int64_t)b * AS + rank;
+                const float c = (float)cls * kMaxWh;
+                S.rb[r] = make_rbox(x + c, y + c, ww, hh, t);
+                float *sb = S.sbox + r * 5;
+                sb[0] = x; sb[1] = y; sb[2] = ww; sb[3] = hh; sb[4] = t;
+                S.sscore[r] = si;
+                S.scls[r] = (uint8_t)cls;
+            }
+        }
+    }
+}
+
+// Fast-NMS rows of a flagged tile: one wave per row, rows interleaved over gridDim.y * 4 waves
+__global__ __launch_bounds__(256) void k_heavy_nms(int A, float iou_thres, int max_nms, float kq, float bdmax, HeavyScratch S) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gw = blockIdx.y * 4 + (tid >> 6), nw = gridDim.y * 4;
+    const int64_t AS = (A + 3) & ~3;
+    const bool skip_other_cls = iou_thres > 1e-3f;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const int n = min(S.ncand[b], max_nms);
+        const RBox *rb = S.rb + (int64_t)b * AS;
+        const uint8_t *scls = S.scls + (int64_t)b * AS;
+        uint8_t *keep = S.keep + (int64_t)b * AS;
+        for (int r = gw; r < n; r += nw) {
+            const RBox q = rb[r];
+            const uint8_t cq = scls[r];
+            bool hit = false;
+            for (int i0 = 0; i0 < r; i0 += 64) {
+                const int i = i0 + lane;
+                bool hh = false;
+                if (i < r && !(skip_other_cls && scls[i] != cq)) {
+                    const RBox p = rb[i];
+                    if (!far_apart(p, q, kq)) {
+                        const int dec = bdmax > 0.0f ? probiou_fast_decision(p, q, bdmax) : 0;
+                        hh = dec > 0 || (dec == 0 && probiou(p, q) >= iou_thres);
+                    }
+                }
+                if (__ballot(hh)) { hit = true; break; }
+            }
+            if (lane == 0) keep[r] = (uint8_t)!hit;
+        }
+    }
+}
+
+// first max_det survivors of a flagged tile in score order -> output rows
+__global__ __launch_bounds__(256) void k_heavy_out(int A, int max_det, int max_nms, HeavyScratch S, float *__restrict__ out, int32_t *__restrict__ count) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x;
+    const int64_t AS = (A + 3) & ~3;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const int n = min(S.ncand[b], max_nms);
+        const uint8_t *keep = S.keep + (int64_t)b * AS;
+        float *ob = out + (int64_t)b * max_det * 7;
+        int m = 0;
+        for (int r0 = 0; r0 < n && m < max_det; r0 += 256) {
+            const int r = r0 + tid;
+            const bool flag = (r < n) && keep[r];
+            const int slot = ordered_slot(flag, wave_tot, m);
+            if (flag && slot < max_det) {
+                const int64_t g = (int64_t)b * AS + r;
+                const float *sb = S.sbox + g * 5;
+                float *o = ob + (int64_t)slot * 7;
+                o[0] = sb[0]; o[1] = sb[1]; o[2] = sb[2]; o[3] = sb[3];
+                o[4] = S.sscore[g]; o[5] = (float)S.scls[g]; o[6] = sb[4];
+            }
+        }
+        if (tid == 0) count[b] = m < max_det ? m : max_det;
+        __syncthreads();
+    }
 }
 
 // stand-alone Fast-NMS on a caller-provided candidate list (parity tap): boxes [n,5], scores [n]
@@ -425,7 +709,7 @@ int obb_decode(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w,
     if (rc) return rc;
     if (B == 0) return OBB_OK;
     OBB_REQUIRE(ctx, head && pred, "obb_decode: NULL buffer");
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)s, head, B, A, nc, h, w, pred);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, (hipStream_t)s, head, B, A, nc, h, w, pred, (const int32_t *)nullptr);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }
@@ -438,15 +722,62 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
     if (rc) return rc;
     if (B == 0) return OBB_OK;
     OBB_REQUIRE(ctx, head && out && count, "obb_decode_nms: NULL buffer");
-    float *pred = (float *)ctx->workspace(WS_GEOM_C, sizeof(float) * (size_t)B * A * (4 + nc + 1));
-    if (!pred) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
+    OBB_REQUIRE(ctx, nc <= 255, "obb_decode_nms: nc > 255 unsupported");
+    hipStream_t st = (hipStream_t)s;
+    const size_t rows = (size_t)B * ((A + 3) & ~3);
+    HeavyScratch S;
+    S.cand = (int32_t *)ctx->workspace(WS_NMS_A, rows * 4);
+    S.cscore = (float *)ctx->workspace(WS_NMS_B, rows * 4);
+    S.sscore = (float *)ctx->workspace(WS_NMS_C, rows * 4);
+    S.sbox = (float *)ctx->workspace(WS_NMS_D, rows * 20);
+    S.rb = (RBox *)ctx->workspace(WS_GEOM_A, rows * sizeof(RBox));
+    uint8_t *bytes = (uint8_t *)ctx->workspace(WS_GEOM_B, rows * 3);
+    int32_t *ints = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)2 * B + 64));
+    if (!S.cand || !S.cscore || !S.sscore || !S.sbox || !S.rb || !bytes || !ints) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
+    S.ccls = bytes; S.scls = bytes + rows; S.keep = bytes + 2 * rows;
+    S.ncand = ints; S.flist = ints + B; S.nflag = ints + 2 * (size_t)B;
+    OBB_HIP(ctx, hipMemsetAsync(S.nflag, 0, sizeof(int32_t), st));
+    // largest logit an anchor needs to be worth the exact class scores: logit(conf) minus a guard band far above the error of sigmoid_f
+    float gate = -INFINITY;
+    if (conf_thres > 0.0f && conf_thres < 1.0f) {
+        const double L = log((double)conf_thres / (1.0 - (double)conf_thres));
+        gate = (float)(L - 1e-3 - 1e-4 * fabs(L));
+    } else if (conf_thres >= 1.0f) gate = INFINITY;
+    const float kq = far_apart_factor(iou_thres), bdmax = probiou_bdmax(iou_thres);
+    if (nc <= 16) hipLaunchKernelGGL(k_cand_nms<true>, dim3((unsigned)B), dim3(256), 0, st, head, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
+    else hipLaunchKernelGGL(k_cand_nms<false>, dim3((unsigned)B), dim3(256), 0, st, head, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
+    OBB_LAUNCH_CHECK(ctx);
+    // tiles above kCandCap candidates (device-side list; every block of these launches exits at once when the list is empty)
+    const int slots = std::min<int>(kHeavySlots, B);
+    hipLaunchKernelGGL(k_heavy_sort, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, 30000, S);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_heavy_nms, dim3((unsigned)slots, 64), dim3(256), 0, st, A, iou_thres, 30000, kq, bdmax, S);
+    OBB_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_heavy_out, dim3((unsigned)slots), dim3(256), 0, st, A, max_det, 30000, S, out, count);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+// The full form: decode every anchor, then one workgroup per tile with every per-candidate array resident in LDS (or in global scratch for
+// inputs too large).  obb_decode_nms used to run this; it stays as an independent implementation that the parity tests compare the
+// candidate-first path with (same rows, bit for bit).
+int obb_decode_nms_full(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres, int32_t max_det,
+                        float *out, int32_t *count, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0 && max_det > 0, "obb_decode_nms_full: bad arguments");
+    int32_t nc = 0, A = 0;
+    int rc = obb_model_info(ctx, h, w, &nc, nullptr, &A, nullptr);
+    if (rc) return rc;
+    if (B == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, head && out && count, "obb_decode_nms_full: NULL buffer");
+    OBB_REQUIRE(ctx, nc <= 255, "obb_decode_nms_full: nc > 255 unsupported");
+    float *pred = (float *)ctx->workspace(WS_GEOM_D, sizeof(float) * (size_t)B * A * (4 + nc + 1));
+    if (!pred) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms_full: workspace allocation failed");
     NmsScratch S;
     rc = nms_scratch(ctx, B, A, S);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, st, head, B, A, nc, h, w, pred);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)cdiv((int64_t)B * A, 256)), dim3(256), 0, st, head, B, A, nc, h, w, pred, (const int32_t *)nullptr);
     OBB_LAUNCH_CHECK(ctx);
-    OBB_REQUIRE(ctx, nc <= 255, "obb_decode_nms: nc > 255 unsupported");
     size_t lds = (size_t)A * (sizeof(RBox) + 12 + 3) + 96;
     if (lds <= 159 * 1024) {
         static bool attr_set = false;
@@ -455,10 +786,10 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
             attr_set = true;
         }
         hipLaunchKernelGGL(k_nms_tile<true>, dim3((unsigned)B), dim3(1024), lds, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
-                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count);
+                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count, 0);
     } else {
         hipLaunchKernelGGL(k_nms_tile<false>, dim3((unsigned)B), dim3(1024), 0, st, (const float *)pred, A, nc, conf_thres, iou_thres, max_det,
-                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count);
+                           30000, far_apart_factor(iou_thres), probiou_bdmax(iou_thres), S, out, count, 0);
     }
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;

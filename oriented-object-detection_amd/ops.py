@@ -153,6 +153,11 @@ def _decode_nms(head: T, h: int, w: int, conf: float, iou: float, max_det: int, 
     _call("obb_decode_nms", ctx(head.device), _p(head), head.shape[0], h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
 
 
+@_op("decode_nms_full", ("det", "count"))
+def _decode_nms_full(head: T, h: int, w: int, conf: float, iou: float, max_det: int, det: T, count: T) -> None:
+    _call("obb_decode_nms_full", ctx(head.device), _p(head), head.shape[0], h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
+
+
 @_op("probiou_nms", ("order", "keep"))
 def _probiou_nms(boxes: T, scores: T, iou: float, order: T, keep: T) -> None:
     _call("obb_probiou_nms", ctx(boxes.device), _p(boxes), _p(scores), boxes.shape[0], float(iou), _p(order), _p(keep), _stream())
@@ -405,14 +410,15 @@ def decode(head, h, w):
     return pred
 
 
-def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300):
-    """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B])"""
+def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False):
+    """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B]).  full=True runs the reference form (decode
+    every anchor first) that the candidate-first default must reproduce bit for bit."""
     hd = _padded_head(_chk(head, torch.float32, "head"))
     B = hd.shape[0]
     det = torch.zeros((B, max_det, 7), dtype=torch.float32, device=hd.device)
     count = torch.zeros(B, dtype=torch.int32, device=hd.device)
     if B:
-        _O.decode_nms(hd, h, w, float(conf), float(iou), int(max_det), det, count)
+        (_O.decode_nms_full if full else _O.decode_nms)(hd, h, w, float(conf), float(iou), int(max_det), det, count)
     return det, count
 
 

@@ -58,6 +58,32 @@ def test_decode_nms_matches_oracle(ops, net, conf, B):
         assert int(count[0]) == 300  # max_det reached in metrics mode
 
 
+@pytest.mark.parametrize("conf,max_det", [(0.25, 300), (0.05, 300), (0.001, 300), (0.25, 5), (0.999999, 300)])
+def test_candidate_first_path_equals_the_full_decode(ops, net, conf, max_det):
+    """obb_decode_nms (conf filter on the class logits -> decode + NMS of the survivors only; tiles above 256 candidates finished by the
+    row-parallel kernels) against obb_decode_nms_full (decode every anchor, one LDS-resident workgroup per tile): identical rows and
+    counts, bit for bit, on tiles with a handful of candidates, with hundreds, and with every anchor a candidate."""
+    h = w = 416
+    B = 12
+    head = _head(net, 5, B, h, w).cuda()
+    head[3, :, 64:76] -= 6.0    # a tile with few candidates
+    head[4, :, 64:76] -= 30.0   # and one with none
+    head[5, :, 64:76] += 3.0    # a saturated tile: (almost) every anchor passes
+    det, cnt = ops.decode_nms(head, h, w, conf, 0.7, max_det)
+    det_f, cnt_f = ops.decode_nms(head, h, w, conf, 0.7, max_det, full=True)
+    assert torch.equal(cnt, cnt_f), (cnt.tolist(), cnt_f.tolist())
+    for b in range(B):
+        n = int(cnt[b])
+        assert torch.equal(det[b, :n], det_f[b, :n]), b
+    c = cnt.cpu().numpy()
+    print("conf", conf, "rows per tile", c.tolist())
+    if conf == 0.25 and max_det == 300:
+        pred = ops.decode(head, h, w)
+        ncand = (pred[..., 4:16].amax(-1) > conf).sum(1).cpu().numpy()
+        print("candidates per tile", ncand.tolist())
+        assert ncand.min() == 0 and ncand.max() > 2048 and ((ncand > 0) & (ncand <= 256)).any() and ((ncand > 256) & (ncand < 2048)).any()
+
+
 def test_probiou_nms_keep_mask_vs_oracle(ops):
     rng = np.random.default_rng(0)
     for n in (1, 7, 300, 2000):

@@ -58,10 +58,15 @@ struct ConvParams {
 // VCAT: 1x1 over a virtual [upsample | skip] concat (ConvParams::up_c); a separate instantiation so that the plain kernels stay branch-free
 // T16: the trailing 1x1 has an activation and a 16-bit (possibly channel-blocked) output of its own -- the cv1 of the C3k2 block behind a
 // stride-2 backbone conv: its result replaces the staged tile in LDS and leaves through the same coalesced write-out.
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false>
+// WRES: "weights resident": a 3x3 stride-1 layer with <= 64 input channels staged as ONE channel stage (CK = cin).  The whole weight
+// block of the group's couts (<= 72 KiB) is copied into LDS once and stays there for every tile the group walks, and a tile's input
+// (13 x 13 + halo, all channels) is ONE set of loads, prefetched into registers a whole tile ahead.  The multi-stage form pays a
+// global-memory latency per 16-channel stage (4 per tile at cin = 64) with 60 MFMAs of cover each; here a tile is 216 MFMAs back to
+// back behind a single, fully covered latency.  One group per CU (104 KiB of LDS), one wave per SIMD: no register limit to respect.
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false, bool WRES = false>
 // Register budget: the 64-cout 3x3 variants need ~210 VGPRs (two waves per SIMD); everything else fits 168 without spills, which is the
 // difference between two and three resident waves per SIMD (allocation granule 8: 170 registers already drop to two).
-__global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2 : 3) void k_conv_igemm(const ConvParams P) {
+__global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2 : 3)) void k_conv_igemm(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) bf16_t s_lut[IN_U8 ? 256 : 8];  // u8 -> half(v/255); sized in multiples of 16 B (statics precede the dynamic region)
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
         ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
     }
     // staging plan: this thread moves the 16-B chunks idx = tid + k*256 of the [in_px][CK] tile
-    constexpr int MAXLD = (KS == 1) ? 4 : 6;
+    constexpr int MAXLD = WRES ? 8 : ((KS == 1) ? 4 : 6);
     constexpr unsigned NOPIX = 0xffffffffu;
     int ipos[MAXLD];  // (iy << 16 | ix) inside the input tile, or -1
     if constexpr (!IN_U8) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
     };
     // Weights of one channel stage (kst * NF fragments of 1 KiB, already in MFMA A-operand lane order) go through LDS too: the
     // group fetches them ONCE (not once per wave), a whole stage ahead, so neither the L1/TA path nor L2 latency sits in the k-loop.
-    constexpr int MAXW = (KS == 1) ? (NF + 1) / 2 : (NF * 5 * 64 + 255) / 256;  // 1x1: CK <= 64 (kst <= 2); 3x3: CK <= 16 (kst <= 5)
+    constexpr int MAXW = WRES ? 1 : ((KS == 1) ? (NF + 1) / 2 : (NF * 5 * 64 + 255) / 256);  // 1x1: CK <= 64 (kst <= 2); 3x3: CK <= 16 (kst <= 5)
     const int nwchunk = P.kst * NF * 64;  // 16-B chunks of weights per stage
     u32x4 prew[MAXW];
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.wpk, 0, (int)P.w_bytes, 0x00020000);
@@ -262,10 +267,13 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
     };
 
     if (t0 >= t1) return;
-    load_w(0);
+    if constexpr (WRES) {  // the whole (single-stage) weight block of this cout group, once
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(P.wpk) + (size_t)cb * nwchunk;
+        for (int i = tid; i < nwchunk; i += 256) *reinterpret_cast<u32x4 *>(wlds + i * 16) = wsrc[i];
+    } else load_w(0);
     if constexpr (!IN_U8) { plan_tile(t0); load_stage(0); }
     else load_u8(t0);
-    bool w_resident = false;
+    bool w_resident = WRES;
 
     for (int t = t0; t < t1; ++t) {
         int b, oy0, ox0;
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(256, (NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2
                 __syncthreads();
                 // prefetch into registers: the next channel stage of this tile, or stage 0 of the next tile; the HBM/L2 latency
                 // hides under this stage's MFMAs (and under the epilogue)
-                if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
+                if constexpr (WRES) { if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); } }
+                else if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
                 else if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); if (P.nstage > 1) load_w(0); }
             }
 
@@ -563,6 +572,11 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) 
     if (ck < 8) ck = 8;
     if (stride == 2 && ck > 16) ck = 16;             // keep the (2T+1)^2 halo tile small enough for several groups per CU
     t.CK = ck;
+    // weights-resident single-stage form (WRES): 3x3 stride 1 on 13 x 13 tiles with 32 or 64 input channels
+    // (measured per 256 tiles: 64 -> 16 couts at 52^2 60.9 -> 50.4 us, 64 -> 32 at 26^2 24.6 -> 23.6 us; the 64-cout groups (104 KiB of LDS, one
+    //  group per CU) gained nothing -- 112.6 -> 115.7 us -- so they keep the 16-channel stages: their k loop is bound by LDS operand
+    //  reads, 7 KiB per 12 MFMAs and wave, not by the per-stage global-memory latency)
+    if (stride == 1 && t.MF == 3 && (cin == 32 || cin == 64) && (t.NF == 2 || t.NF == 1)) t.CK = cin;
     return t;
 }
 
@@ -597,6 +611,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
 }
 
 static bool conv_multi_stage(const ConvLaunch &L) { return (L.in_u8 ? 8 : L.cin) > L.CK; }
+static bool conv_wres(const ConvLaunch &L) { return L.ks == 3 && L.CK > 16; }
 
 // LDS layout: [input tile (one channel stage) | weights of the stage].  The epilogue's output staging starts at offset 0; for
 // multi-stage layers it may run over the weights as well (they are re-staged at every stage anyway), single-stage layers keep
@@ -628,8 +643,33 @@ bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act1
     return (ks == 3 && MF == 3 && NF == 4 && nf2 == 4) || (ks == 3 && MF == 3 && NF == 1 && nf2 == 1) || (ks == 1 && MF == 2 && NF == 4 && nf2 == 1);
 }
 
+template <typename K>
+static hipError_t launch_big_lds(K kernel, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;  // one flag per kernel instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);  // + the static arrays (bias, LUT) <= 160 KiB
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
 template <int KS, int MF, int NF, bool F16>
 static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if constexpr (KS == 3 && MF == 3) {
+        if (conv_wres(L)) {  // weights-resident single-stage form: plain / 16-bit tail (T16) / fp32 head tail
+            if (L.tail_cout > 0 && L.tail_act16) return hipErrorInvalidValue;  // (the fused cv1 sits behind stride-2 convs only)
+            if (L.tail_cout > 0) {
+                constexpr int T = NF == 4 ? 4 : 1;
+                if constexpr (NF == 4 || NF == 1) {
+                    if (tail_nf(L.tail_cout) != T) return hipErrorInvalidValue;
+                    return launch_big_lds(k_conv_igemm<KS, MF, NF, false, false, F16, T, false, false, true>, P, grid, lds, st);
+                } else return hipErrorInvalidValue;
+            }
+            return launch_big_lds(k_conv_igemm<KS, MF, NF, false, false, F16, 0, false, false, true>, P, grid, lds, st);
+        }
+    }
     if (L.tail_cout > 0 && L.tail_act16) {  // stride-2 backbone conv + the cv1 of the following C3k2 block
         if constexpr (KS == 3 && MF == 3 && (NF == 2 || NF == 4)) {
             if (L.in_u8 || L.out_f32 || tail_nf(L.tail_cout) != NF) return hipErrorInvalidValue;
@@ -755,7 +795,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
         if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = (unsigned)span;
         P.w_bytes = (unsigned)wb;
-        if (L.ks == 3 && L.CK > 16) return hipErrorInvalidValue;
+        if (conv_wres(L) && (L.stride != 1 || L.MF != 3 || L.CK != L.cin || (L.cin != 32 && L.cin != 64) || L.in_u8 || L.out_f32 || L.up_c > 0)) return hipErrorInvalidValue;
     }
     int TWin = (L.TW - 1) * L.stride + L.ks;
     P.inv_twin = 1.0f / (float)TWin;
@@ -763,7 +803,7 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     if ((1 << P.sh) != L.CK / 8 || L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
     {
         int THin = (L.TH - 1) * L.stride + L.ks;
-        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > (L.ks == 1 ? 4 : 6) * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
+        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > (conv_wres(L) ? 8 : (L.ks == 1 ? 4 : 6)) * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
         if (L.ks == 1 && L.CK > 64) return hipErrorInvalidValue;
     }
     int ncb = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
@@ -774,10 +814,11 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     static const int tpw_max = getenv("OBB_TPW") ? atoi(getenv("OBB_TPW")) : 8;
     int64_t tpw = ntiles * ncb / (256 * 8);
     P.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(tpw, tpw_max));
+    if (conv_wres(L)) P.tpw = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles * ncb / (256 * 2), 16));  // one group per CU: two rounds of groups, <= 16 tiles each
     P.gx = (int)((ntiles + P.tpw - 1) / P.tpw); P.ncb = ncb;
     dim3 grid((unsigned)((P.gx + 7) / 8 * 8 * ncb));  // 1-D: see the XCD-aware decoding at the top of the kernel
     size_t lds = conv_lds_bytes(L);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > (conv_wres(L) ? 152 : 64) * 1024) return hipErrorInvalidValue;
     if (L.ks == 3) {
         switch (L.MF) {
             case 1: return launch_nf<3, 1>(L, P, grid, lds, st);

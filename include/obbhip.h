@@ -170,6 +170,13 @@ int obb_probiou_nms(obb_ctx *ctx, const float *boxes, const float *scores, int64
  * lb float[n*3] = (gain, pad_x, pad_y) or NULL for identity.  xywhr float[n*5], pts float[n*8]. */
 int obb_results(obb_ctx *ctx, const float *det, const float *lb, int64_t n, float *xywhr, float *pts, obb_stream_t s);
 
+/* ------------------------------------------------------------------ f1 (first slice): the ProbIoU rotated-box loss of the training step */
+/* `model.train(...)` (Train_OBB.py:796-841) -> ultralytics v8OBBLoss -> RotatedBboxLoss: loss_iou = sum((1 - probiou(pred, target)) * weight)
+ * / target_scores_sum over the n matched (prediction, target) pairs, forward and backward in one pass.  pred, target float[n*5] rows
+ * (x, y, w, h, theta); weight float[n] (NULL = 1); *loss (device float) receives the scalar, grad_pred float[n*5] = d loss / d pred. */
+int obb_probiou_loss(obb_ctx *ctx, const float *pred, const float *target, const float *weight, int64_t n, float target_scores_sum,
+                     float *loss, float *grad_pred, obb_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,9 @@
 //   * the input tile (+ halo, zero padding written as zeros) is staged in LDS one channel stage at a time; weights stream from L2 in
 //     fragment order (1 KiB per wave-instruction), prefetched one k step ahead.  No software pipelining of the staging: at 1/16 of the
 //     fp16 MFMA rate a stage computes for 6-15 us, and two or three resident workgroups per CU cover each other's staging phases.
+//   * measured and dropped: prefetching the next channel stage into registers under the MFMAs (176 VGPRs -> two waves per SIMD
+//     instead of three: 40.1 -> 42.1 ms per 1024 tiles), and dword loads of 4-pixel groups + an LDS table for the uint8 input layer
+//     (596 -> 771 us per 256 tiles).
 //   * epilogue: + bias, SiLU (expf + IEEE division, like torch), + residual, fp32 store into a channel slice of the consumer's buffer.
 #include "f32path.h"
 

@@ -168,6 +168,11 @@ def _results(det: T, lb: Optional[T], xywhr: T, pts: T) -> None:
     _call("obb_results", ctx(det.device), _p(det), _p(lb), det.shape[0], _p(xywhr), _p(pts), _stream())
 
 
+@_op("probiou_loss", ("loss", "grad_pred"))
+def _probiou_loss(pred: T, target: T, weight: Optional[T], target_scores_sum: float, loss: T, grad_pred: T) -> None:
+    _call("obb_probiou_loss", ctx(pred.device), _p(pred), _p(target), _p(weight), pred.shape[0], float(target_scores_sum), _p(loss), _p(grad_pred), _stream())
+
+
 @_op("debug_activation", ("out",))
 def _debug_activation(name: str, B: int, h: int, w: int, out: T) -> None:
     n = C.c_int64(0)
@@ -476,3 +481,18 @@ def letterbox(image, x, y, x2, y2, imgsz):
     out = torch.empty((p["out_h"], p["out_w"], Cc), dtype=torch.uint8, device=img.device)
     _O.letterbox(img, int(x), int(y), int(x2), int(y2), int(imgsz), out)
     return out, p
+
+
+def probiou_loss(pred, target, weight=None, target_scores_sum=1.0):
+    """ProbIoU rotated-box loss of n matched pairs, forward + backward in one launch: pred, target [n,5] (x,y,w,h,theta) float32,
+    weight [n] or None -> (loss float32[1], grad_pred [n,5] = d loss / d pred).  Train_OBB.py:796-841 -> v8OBBLoss / RotatedBboxLoss."""
+    p = _chk(pred, torch.float32, "pred").reshape(-1, 5)
+    t = _chk(target, torch.float32, "target").reshape(-1, 5)
+    if p.shape != t.shape:
+        raise ValueError("probiou_loss: shape mismatch")
+    if weight is not None:
+        weight = _chk(weight, torch.float32, "weight").reshape(-1)
+    loss = torch.zeros(1, dtype=torch.float32, device=p.device)
+    grad = torch.empty_like(p)
+    _O.probiou_loss(p, t, weight, float(target_scores_sum), loss, grad)
+    return loss, grad

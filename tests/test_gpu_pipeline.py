@@ -153,3 +153,37 @@ def test_process_image_dual_scale_vs_oracle(ood, nets):
     got1 = ood.detect.process_image(img, None, [nets["m416"]], cfg)
     exp1, _ = opl.process_image(img, oms[1:], (416,), (100,))
     _compare_dets(got1, exp1)
+
+
+def test_process_image_on_the_real_sample_file(ood, nets, tmp_path):
+    """BASELINE configs[0] plumbing: process_image(path, output_dir, ...) on the reference's own Input/Test1.png (committed fixture): image
+    decode -> 9 + 90 tiles -> ... -> CSV rows; equals the CPU pipeline fed with the same network outputs; the I/O shell then writes the
+    overlay JPEG and the xlsx table of Detect_OBB.py:295-330."""
+    import os
+    from conftest import GOLDEN
+    from oriented_object_detection_amd import io_shell
+    path = os.path.join(GOLDEN, "input", "Test1.png")
+    img = ood.detect.imread_bgr(path)
+    assert img.shape == (807, 895, 3)
+
+    def hf(model):
+        def f(t):
+            model._ensure_active()
+            return ood.ops.forward(torch.as_tensor(t).cuda()).cpu()[..., :77]
+        return f
+    oms = [opl.OracleModel(nets["n128"], 128, head_fn=hf(nets["m128"])), opl.OracleModel(nets["n416"], 416, head_fn=hf(nets["m416"]))]
+    exp, by_scale = opl.process_image(img, oms)
+    got = ood.detect.process_image(path, str(tmp_path), [nets["m128"], nets["m416"]])
+    assert len(exp) > 3
+    _compare_dets(got, exp)
+    rows = [l.rstrip("\n").split(",") for l in open(tmp_path / "Test1.csv")]
+    assert rows[0] == io_shell.XLSX_COLUMNS and len(rows) == len(got) + 1
+    jpg, xlsx = io_shell.save_outputs(img, path, str(tmp_path), got, ood.detect.DEFAULT.CLASS_NAMES)
+    assert os.path.getsize(jpg) > 10000
+    back = io_shell.read_xlsx(xlsx)
+    assert len(back) == len(got) + 1 and [float(v) for v in back[1][1:9]] == [float(v) for v in got[0][:8]]
+    # the script's main loop over an input directory (Detect_OBB.py:745-755)
+    os.makedirs(tmp_path / "in")
+    os.symlink(path, tmp_path / "in" / "Test1.png")
+    done = io_shell.main(str(tmp_path / "in"), str(tmp_path / "out"), [nets["m128"], nets["m416"]])
+    assert len(done) == 1 and os.path.exists(tmp_path / "out" / "Test1.xlsx") and os.path.exists(tmp_path / "out" / "Test1_detected.jpg")

@@ -152,6 +152,188 @@ __device__ __forceinline__ bool meta_overlap(const BoxMeta &a, const BoxMeta &b)
     return a.x0 <= a.x1 && b.x0 <= b.x1 && !(a.x1 < b.x0 || b.x1 < a.x0 || a.y1 < b.y0 || b.y1 < a.y0);
 }
 
+// ---- bucketed form of the same sort (n >= kBucketSortMin): O(n) instead of O(n^2) compares.
+// The monotone uint64 images are spread over kSortBuckets equal key ranges between the batch's smallest and largest image (a
+// data-adaptive most-significant digit: confidences live in [0.25, 1], a fixed digit of the float format would use a handful of
+// buckets).  rank(i) = (elements in higher buckets) + (elements of i's own bucket that precede it: larger key, or equal key and smaller
+// index) -- the same stable descending order, element for element.  Buckets hold n / 65536 elements on average, so the in-bucket count
+// is a few compares; a batch of all-equal keys degenerates to one bucket = the O(n^2) count it replaces.
+static constexpr int kSortBuckets = 65536;
+static constexpr int64_t kBucketSortMin = 8192;
+
+struct SortInfo { unsigned long long lo; int shift; };
+
+__global__ __launch_bounds__(1024) void k_sort_range(const double *__restrict__ key, int64_t n, SortInfo *__restrict__ info) {
+    __shared__ unsigned long long smin[1024], smax[1024];
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { const unsigned long long u = sort_image(key[i]); lo = u < lo ? u : lo; hi = u > hi ? u : hi; }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            if (smin[threadIdx.x + d] < smin[threadIdx.x]) smin[threadIdx.x] = smin[threadIdx.x + d];
+            if (smax[threadIdx.x + d] > smax[threadIdx.x]) smax[threadIdx.x] = smax[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long range = smax[0] - smin[0];
+        int sh = 0;
+        while (sh < 63 && (range >> sh) >= (unsigned long long)kSortBuckets) ++sh;
+        info->lo = smin[0]; info->shift = sh;
+    }
+}
+
+__device__ __forceinline__ int sort_bucket(unsigned long long u, const SortInfo &I) {
+    return kSortBuckets - 1 - (int)((u - I.lo) >> I.shift);  // bucket 0 holds the LARGEST keys (descending order)
+}
+
+__global__ __launch_bounds__(256) void k_sort_count(const double *__restrict__ key, int64_t n, const SortInfo *__restrict__ info, int32_t *__restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&hist[sort_bucket(sort_image(key[i]), *info)], 1);
+}
+
+// exclusive prefix sum of `cnt` cells (one workgroup); start[cnt] = total; cursor = copy of start (scatter positions; may alias hist).
+// Each thread owns a run of consecutive cells: local sums -> one block-wide scan of the 1024 partial sums -> local prefix.
+__global__ __launch_bounds__(1024) void k_cells_scan(const int32_t *hist, int cnt, int32_t *__restrict__ start, int32_t *cursor) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (cnt + 1023) / 1024;
+    const int c0 = tid * per, c1 = min(c0 + per, cnt);
+    int local = 0;
+    for (int c = c0; c < c1; ++c) local += hist[c];
+    int incl = local;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = incl - local;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    for (int c = c0; c < c1; ++c) { const int v = hist[c]; start[c] = before; cursor[c] = before; before += v; }
+    if (tid == 1023) start[cnt] = before;  // (the last thread's running sum ends at the total: empty runs add nothing)
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(const double *__restrict__ key, int64_t n, const SortInfo *__restrict__ info, int32_t *__restrict__ cursor,
+                                                     int32_t *__restrict__ members) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    members[atomicAdd(&cursor[sort_bucket(sort_image(key[i]), *info)], 1)] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_sort_rank(const double *__restrict__ key, int64_t n, const SortInfo *__restrict__ info, const int32_t *__restrict__ start,
+                                                  const int32_t *__restrict__ members, int32_t *__restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long ki = sort_image(key[i]);
+    const int b = sort_bucket(ki, *info);
+    const int lo = start[b], hi = start[b + 1];
+    int r = lo;
+    for (int m = lo; m < hi; ++m) {
+        const int j = members[m];
+        const unsigned long long kj = sort_image(key[j]);
+        r += (kj > ki) | ((kj == ki) & (j < (int)i));
+    }
+    order[r] = (int32_t)i;
+}
+
+// ---- suppression pairs of the dense merge through a uniform grid (n >= kGridMin, thr > 0): a pair can only overlap if the envelope
+// centres are closer than the largest envelope extent in both axes, so with cells at least that large every partner of a box sits in
+// the 3 x 3 cells around it.  Replaces the all-pairs envelope test (n^2 / 2) of k_nms_mask<EDGES> by ~9 cells x occupancy tests per box;
+// the exact IoU runs on the same candidate set (same class, envelopes not disjoint), so the edge list is the same set of pairs.
+static constexpr int kGridDim = 256;  // cells per axis at most
+static constexpr int64_t kGridMin = 8192;
+
+struct GridInfo { double ox, oy, inv_cell; int gw, gh; };
+
+__global__ __launch_bounds__(1024) void k_grid_info(const BoxMeta *__restrict__ meta, int64_t n, GridInfo *__restrict__ info) {
+    __shared__ double s0[1024], s1[1024], s2[1024], s3[1024], s4[1024];
+    double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY, ext = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const BoxMeta m = meta[i];
+        if (!(m.x0 <= m.x1)) continue;  // invalid quad: empty envelope, never a partner
+        x0 = fmin(x0, m.x0); y0 = fmin(y0, m.y0); x1 = fmax(x1, m.x1); y1 = fmax(y1, m.y1);
+        ext = fmax(ext, fmax(m.x1 - m.x0, m.y1 - m.y0));
+    }
+    s0[threadIdx.x] = x0; s1[threadIdx.x] = y0; s2[threadIdx.x] = x1; s3[threadIdx.x] = y1; s4[threadIdx.x] = ext;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s0[threadIdx.x] = fmin(s0[threadIdx.x], s0[threadIdx.x + d]); s1[threadIdx.x] = fmin(s1[threadIdx.x], s1[threadIdx.x + d]);
+            s2[threadIdx.x] = fmax(s2[threadIdx.x], s2[threadIdx.x + d]); s3[threadIdx.x] = fmax(s3[threadIdx.x], s3[threadIdx.x + d]);
+            s4[threadIdx.x] = fmax(s4[threadIdx.x], s4[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        GridInfo g;
+        if (!(s0[0] <= s2[0])) { g.ox = g.oy = 0.0; g.inv_cell = 0.0; g.gw = g.gh = 1; }
+        else {
+            const double wx = s2[0] - s0[0], wy = s3[0] - s1[0];
+            double cell = fmax(s4[0], fmax(wx, wy) / (double)(kGridDim - 1));
+            cell = cell > 0.0 ? cell * (1.0 + 1e-9) : 1.0;  // (a hair larger than the largest extent: centre distance < cell for overlapping envelopes)
+            g.ox = s0[0]; g.oy = s1[0]; g.inv_cell = 1.0 / cell;
+            g.gw = min(kGridDim, (int)(wx / cell) + 1); g.gh = min(kGridDim, (int)(wy / cell) + 1);
+        }
+        *info = g;
+    }
+}
+
+__device__ __forceinline__ int grid_cell(const BoxMeta &m, const GridInfo &g, int &cx, int &cy) {
+    cx = (int)(((m.x0 + m.x1) * 0.5 - g.ox) * g.inv_cell); cy = (int)(((m.y0 + m.y1) * 0.5 - g.oy) * g.inv_cell);
+    cx = cx < 0 ? 0 : (cx >= g.gw ? g.gw - 1 : cx); cy = cy < 0 ? 0 : (cy >= g.gh ? g.gh - 1 : cy);
+    return cy * g.gw + cx;
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(const BoxMeta *__restrict__ meta, int64_t n, const GridInfo *__restrict__ info, int32_t *__restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const BoxMeta m = meta[i];
+    if (!(m.x0 <= m.x1)) return;
+    int cx, cy;
+    atomicAdd(&hist[grid_cell(m, *info, cx, cy)], 1);
+}
+
+__global__ __launch_bounds__(256) void k_grid_scatter(const BoxMeta *__restrict__ meta, int64_t n, const GridInfo *__restrict__ info, int32_t *__restrict__ cursor,
+                                                     int32_t *__restrict__ members) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const BoxMeta m = meta[i];
+    if (!(m.x0 <= m.x1)) return;
+    int cx, cy;
+    members[atomicAdd(&cursor[grid_cell(m, *info, cx, cy)], 1)] = (int32_t)i;
+}
+
+// thread = box j (sorted position): partners i < j in the 3 x 3 cells around it -> edge (i, j) when same class and IoU(i, j) >= thr
+__global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ sboxes, const int32_t *__restrict__ scls, const BoxMeta *__restrict__ meta, int64_t n,
+                                                   double thr, const GridInfo *__restrict__ info, const int32_t *__restrict__ start,
+                                                   const int32_t *__restrict__ members, unsigned long long *__restrict__ edges,
+                                                   unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const BoxMeta mj = meta[j];
+    if (!(mj.x0 <= mj.x1)) return;
+    const GridInfo g = *info;
+    int cx, cy;
+    grid_cell(mj, g, cx, cy);
+    const int cj = scls[j];
+    P2 q[4];
+    for (int k = 0; k < 4; ++k) { q[k].x = sboxes[j * 8 + 2 * k]; q[k].y = sboxes[j * 8 + 2 * k + 1]; }
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.gh - 1); ++yy)
+        for (int xx = max(cx - 1, 0); xx <= min(cx + 1, g.gw - 1); ++xx) {
+            const int c = yy * g.gw + xx;
+            for (int m = start[c]; m < start[c + 1]; ++m) {
+                const int i = members[m];
+                if (i >= j || scls[i] != cj || !meta_overlap(meta[i], mj)) continue;
+                P2 p[4];
+                for (int k = 0; k < 4; ++k) { p[k].x = sboxes[(int64_t)i * 8 + 2 * k]; p[k].y = sboxes[(int64_t)i * 8 + 2 * k + 1]; }
+                if (poly_iou_core(p, q) >= thr) {  // (row box first, as k_nms_mask evaluates it)
+                    const unsigned int e = atomicAdd(edge_count, 1u);
+                    if (e < edge_cap) edges[e] = ((unsigned long long)i << 32) | (unsigned long long)j;
+                }
+            }
+        }
+}
+
 // One wave per 64x64 block of the (row i, col j>i) pair matrix.  Phase 1: every lane runs the 64 cheap
 // class+envelope tests of its row.  Phase 2: the surviving pairs are compacted through LDS and clipped one per lane.
 // Output word layout is column-block-major: word (row i, block jb) lives at mask[jb * n + i] so that both this
@@ -754,6 +936,23 @@ int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *or
     OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1ll << 31), "obb_sort_desc_stable: bad n");
     if (n == 0) return OBB_OK;
     OBB_REQUIRE(ctx, key && order, "obb_sort_desc_stable: NULL buffer");
+    if (n >= kBucketSortMin) {  // bucketed O(n) form, same order element for element
+        hipStream_t st = (hipStream_t)s;
+        int32_t *buf = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)n + 2 * (size_t)kSortBuckets + 64));
+        if (!buf) return set_error(ctx, OBB_ERR_HIP, "obb_sort_desc_stable: workspace allocation failed");
+        int32_t *hist = buf, *start = buf + kSortBuckets + 8, *members = buf + 2 * kSortBuckets + 32;
+        SortInfo *info = (SortInfo *)(buf + 2 * kSortBuckets + 16);
+        int32_t *cursor = hist;  // the histogram is dead once scanned: reuse it as the scatter cursor
+        OBB_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int32_t) * kSortBuckets, st));
+        hipLaunchKernelGGL(k_sort_range, dim3(1), dim3(1024), 0, st, key, n, info);
+        hipLaunchKernelGGL(k_sort_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, hist);
+        hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, kSortBuckets, start, cursor);
+        hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, cursor, members);
+        hipLaunchKernelGGL(k_sort_rank, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, (const int32_t *)start,
+                           (const int32_t *)members, order);
+        OBB_LAUNCH_CHECK(ctx);
+        return OBB_OK;
+    }
     int32_t *rank = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * (size_t)n);
     if (!rank) return set_error(ctx, OBB_ERR_HIP, "obb_sort_desc_stable: workspace allocation failed");
     OBB_REQUIRE(ctx, cdiv(n, kRankJSlice) <= 65535, "obb_sort_desc_stable: n too large");
@@ -880,8 +1079,23 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         unsigned int *ecount = (unsigned int *)ctx->workspace(WS_NMS_D, 256);
         if (!edges || !ecount) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
         OBB_HIP(ctx, hipMemsetAsync(ecount, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,
-                           (const BoxMeta *)meta, n, thr, (unsigned long long *)nullptr, edges, ecount, cap);
+        if (n >= kGridMin) {  // candidate partners through a uniform grid instead of all pairs
+            const int ncell = kGridDim * kGridDim;
+            int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * ((size_t)n + 2 * (size_t)ncell + 64));
+            if (!gbuf) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+            int32_t *hist = gbuf, *start = gbuf + ncell + 8, *members = gbuf + 2 * ncell + 32;
+            GridInfo *ginfo = (GridInfo *)(gbuf + 2 * ncell + 16);
+            OBB_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int32_t) * ncell, st));
+            hipLaunchKernelGGL(k_grid_info, dim3(1), dim3(1024), 0, st, (const BoxMeta *)meta, n, ginfo);
+            hipLaunchKernelGGL(k_grid_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist);
+            hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, ncell, start, hist);
+            hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist, members);
+            hipLaunchKernelGGL(k_grid_pairs, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const double *)sboxes, (const int32_t *)scls, (const BoxMeta *)meta, n,
+                               thr, (const GridInfo *)ginfo, (const int32_t *)start, (const int32_t *)members, edges, ecount, cap);
+        } else {
+            hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,
+                               (const BoxMeta *)meta, n, thr, (unsigned long long *)nullptr, edges, ecount, cap);
+        }
         OBB_LAUNCH_CHECK(ctx);
         unsigned int E = 0;
         OBB_HIP(ctx, hipMemcpyAsync(&E, ecount, sizeof E, hipMemcpyDeviceToHost, st));

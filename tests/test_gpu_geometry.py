@@ -67,12 +67,16 @@ def test_iou_matrix(ops):
 
 def test_sort_desc_stable(ops):
     rng = np.random.default_rng(0)
-    for n in (1, 2, 100, 1024, 1025, 5000):
+    for n in (1, 2, 100, 1024, 1025, 5000, 8192, 40000, 150000):  # >= 8192: the bucketed O(n) form must give the same order
         k = rng.uniform(0, 1, n).astype(np.float32).astype(np.float64)
         k[rng.integers(0, n, n // 4 + 1)] = k[0]  # ties
         got = ops.sort_desc_stable(dev(k, torch.float64)).cpu().numpy()
         assert np.array_equal(got, og.sort_desc_stable(k))
         assert np.array_equal(got, np.argsort(-k, kind="stable"))
+    # confidences as the path produces them ([0.25, 1], float32 values), all-equal keys, negative / signed-zero / infinite keys
+    for k in (rng.uniform(0.25, 1, 30000).astype(np.float32).astype(np.float64), np.full(9000, 0.5), np.concatenate([rng.normal(0, 1, 9000), [0.0, -0.0, np.inf, -np.inf, 0.0]])):
+        got = ops.sort_desc_stable(dev(k, torch.float64)).cpu().numpy()
+        assert np.array_equal(got, og.sort_desc_stable(k))
 
 
 def test_merge_matches_reference_goldens(ops, ref_vectors):
@@ -116,6 +120,17 @@ def test_merge_idempotent_at_scale(ops):
     assert np.array_equal(o2.cpu().numpy(), np.arange(len(sel)))  # already conf-sorted
     srt = S[order.long()].cpu().numpy()
     assert np.all(np.diff(srt) <= 0)
+    # the grid-binned pair search (n >= 8192) against the all-pairs bit matrix on the same sorted boxes: identical keep flags; also
+    # with one box as large as the whole map (the grid degenerates to a few huge cells)
+    for huge in (False, True):
+        bb = boxes.copy()
+        if huge:
+            bb[17] = [0, 0, 8192, 0, 8192, 8192, 0, 8192]
+        Bh = dev(bb, torch.float64)
+        order, keep, nk = ops.merge_detections(Bh, Cc, S, 0.4)
+        sb, sc = Bh[order.long()].contiguous(), Cc[order.long()].contiguous()
+        k2, _ = ops.nms_reduce(ops.nms_mask(sb, sc, 0.4), n)
+        assert torch.equal(k2, keep), huge
 
 
 def test_merge_segments_vs_oracle(ops):

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libobbhip.so")
+SO_PATH = os.environ.get("OBB_LIB") or os.path.join(_HERE, "libobbhip.so")  # OBB_LIB: diagnostic builds of the same library (tools/stamp_conv.sh)
 _lib = None
 
 c_dp, c_fp, c_ip, c_lp, c_bp = (C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32),

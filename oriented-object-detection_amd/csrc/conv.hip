@@ -20,6 +20,7 @@
 #include "conv.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -27,6 +28,20 @@
 namespace obb {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Diagnostic build only (-DOBB_STAMPS, tools/stamp_conv.sh): s_memtime stamps around the phases of a tile, summed per wave and added
+// to ConvParams::stamps[0..5] = {barrier wait, LDS staging, prefetch issue, k loop, epilogue, tiles}.  Never compiled into the product.
+#ifdef OBB_STAMPS
+#define STAMP_INIT unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_tiles = 0, st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_TILE ++st_tiles;
+#define STAMP_FLUSH if (P.stamps && lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(P.stamps + i_, st_acc[i_]); atomicAdd(P.stamps + 5, st_tiles); }
+#else
+#define STAMP_INIT
+#define STAMP(i)
+#define STAMP_TILE
+#define STAMP_FLUSH
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector: stays in registers where HIP's uint4 struct may not
 
 struct ConvParams {
@@ -49,6 +64,7 @@ struct ConvParams {
     const void *in2; int in2_cs, in2_co; unsigned in2_span_bytes; int up_c, up_W, up_HW;
     // fused trailing 1x1 conv (TAIL): out2[pixel][cout2] = W2 . y[pixel][0 .. 16*NF) + bias2, fp32 rows of the head tensor
     const bf16_t *w2pk; const float *bias2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, kst2, w2_off;
+    unsigned long long *stamps;  // diagnostic build (-DOBB_STAMPS) only
     int dbg;  // timing experiments only (OBB_CONV_DBG): 1 skip MFMA loop, 2 skip activation loads, 4 skip SiLU, 8 skip stores, 16 skip weight loads
     float inv_twin, inv_tw;
 };
@@ -274,6 +290,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
     if constexpr (!IN_U8) { plan_tile(t0); load_stage(0); }
     else load_u8(t0);
     bool w_resident = WRES;
+    STAMP_INIT
 
     for (int t = t0; t < t1; ++t) {
         int b, oy0, ox0;
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
 
         for (int stage = 0; stage < P.nstage; ++stage) {
             __syncthreads();
+            STAMP(0)
             // ---- stage this channel chunk of the input tile (and, unless resident, the stage's weights) into LDS
             if (!w_resident) store_w();
             if constexpr (IN_U8) {
@@ -295,11 +313,13 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
             } else {
                 store_stage();
                 __syncthreads();
+                STAMP(1)
                 // prefetch into registers: the next channel stage of this tile, or stage 0 of the next tile; the HBM/L2 latency
                 // hides under this stage's MFMAs (and under the epilogue)
                 if constexpr (WRES) { if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); } }
                 else if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
                 else if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); if (P.nstage > 1) load_w(0); }
+                STAMP(2)
             }
 
             // ---- K loop over this stage: weight and activation fragments both come from LDS (ds_read_b128, lane-linear / padded rows)
@@ -354,6 +374,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                 }
             }
         }
+        STAMP(3)
         w_resident = (P.nstage == 1);  // single-stage layers keep their weights in LDS for every following tile
 
         // ---- epilogue: lane owns couts [cbase, cbase + 4*NF) of its pixels: + bias, SiLU, + residual
@@ -543,7 +564,10 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
             __syncthreads();
             write_out(std::integral_constant<int, 2 * NF>(), P.cout, cb * 2 * NF);
         }
+        STAMP(4)
+        STAMP_TILE
     }
+    STAMP_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -721,7 +745,25 @@ static hipError_t launch_nf(const ConvLaunch &L, const ConvParams &P, dim3 grid,
     return hipErrorInvalidValue;
 }
 
+static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned long long **stamps_out);
+
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
+    unsigned long long *sd = nullptr;
+    hipError_t e = launch_conv_impl(L, st, &sd);
+#ifdef OBB_STAMPS
+    if (e == hipSuccess && sd) {  // diagnostic build: synchronise and print this launch's phase sums (cycles per wave and tile)
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, sd, 64, hipMemcpyDeviceToHost);
+        const double n = h[5] ? (double)h[5] : 1.0;
+        fprintf(stderr, "STAMPS k%d s%d cin%d cout%d out%dx%d CK%d MF%d NF%d tail%d | per wave-tile cycles: barrier %.0f  lds_stage %.0f  prefetch %.0f  kloop %.0f  epilogue %.0f  (wave-tiles %.0f)\n",
+                L.ks, L.stride, L.cin, L.cout, L.Hout, L.Wout, L.CK, L.MF, L.NF, L.tail_cout, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n);
+    }
+#endif
+    return e;
+}
+
+static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned long long **stamps_out) {
     ConvParams P;
     P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
     P.out = L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
@@ -770,6 +812,14 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
     static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
     P.dbg = dbg;
+    P.stamps = nullptr;
+#ifdef OBB_STAMPS
+    static unsigned long long *stamp_dev = nullptr;
+    if (!stamp_dev) (void)hipMalloc((void **)&stamp_dev, 64);
+    (void)hipMemsetAsync(stamp_dev, 0, 64, st);
+    P.stamps = stamp_dev;
+    *stamps_out = stamp_dev;
+#endif
     P.in2 = L.in2.p; P.in2_cs = L.in2.cs; P.in2_co = L.in2.co; P.up_c = L.up_c; P.up_W = L.up_W; P.up_HW = L.up_HW; P.in2_span_bytes = 0;
     if (L.up_c > 0) {  // virtual [upsample | skip] concat: 1-D 1x1 launches over plain NHWC sources only
         if (L.ks != 1 || L.in_u8 || L.B != 1 || L.Hin != 1 || L.in.cpb || L.in2.cpb || !L.in2.p || L.up_c % L.CK || L.up_c >= L.cin || (L.up_W & 1) ||

@@ -11,6 +11,7 @@ shutil.copy(O + "/layers32.txt", R + "forward_f32_layers_b256.txt")
 shutil.copy(newest(O + "/prof_f32/*/*_kernel_stats.csv"), R + "bench_f32_kernel_stats_sequential.csv")
 shutil.copy(O + "/postproc.txt", R + "postproc.txt")
 shutil.copy(O + "/merge_scaling.txt", R + "merge_scaling.txt")
+open(R + "conv_phase_stamps.txt", "w").write("# tools/stamp_conv.sh: s_memtime stamps inside k_conv_igemm (diagnostic build), one eager forward of 256 tiles, fp16;\n# cycles per wave and tile spent in: waiting at the top-of-stage barrier | LDS staging (incl. the wait for the prefetched global loads) |\n# issuing the next prefetch | the MFMA k loop | the epilogue (bias, SiLU, stores)\n" + "".join(l for l in open(O + "/stamps.txt") if l.startswith("STAMPS")))
 shutil.copy(newest(O + "/pptrace/*/*_kernel_stats.csv"), R + "decode_nms_kernel_stats.csv")
 KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image", "k_dwpw_stripe", "_f32")
 def load(d):

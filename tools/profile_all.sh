@@ -17,6 +17,8 @@ OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_
 python3 tools/postproc_bench.py > $O/postproc.txt 2> $O/postproc.err
 python3 tools/merge_scaling.py > $O/merge_scaling.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pptrace -- python3 tools/pp_trace.py > $O/pptrace.log 2>&1
+STAMP_TAIL=70 bash tools/stamp_conv.sh > $O/stamps.txt 2>&1
+cd $GRAFT_REPO_ROOT
 grep -h metric $O/bench.json $O/bench_prof_b.log $O/bench_prof_bs.log $O/bench_seq_plain.json $O/bench_nopipe.json $O/bench_prof_f32.log | python3 -c "
 import sys,json
 for l in sys.stdin:

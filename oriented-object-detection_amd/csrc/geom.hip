@@ -195,22 +195,28 @@ __global__ __launch_bounds__(256) void k_sort_count(const double *__restrict__ k
 }
 
 // exclusive prefix sum of `cnt` cells (one workgroup); start[cnt] = total; cursor = copy of start (scatter positions; may alias hist).
-// Each thread owns a run of consecutive cells: local sums -> one block-wide scan of the 1024 partial sums -> local prefix.
+// Each of the 16 waves owns a contiguous segment and walks it 64 cells at a time (coalesced): segment sums -> scan of the 16 sums ->
+// a second walk with a wave prefix scan per 64 cells and a running carry.
 __global__ __launch_bounds__(1024) void k_cells_scan(const int32_t *hist, int cnt, int32_t *__restrict__ start, int32_t *cursor) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (cnt + 1023) / 1024;
-    const int c0 = tid * per, c1 = min(c0 + per, cnt);
+    const int per = ((cnt + 15) / 16 + 63) / 64 * 64;  // cells per wave, a multiple of 64
+    const int c0 = wave * per, c1 = min(c0 + per, cnt);
     int local = 0;
-    for (int c = c0; c < c1; ++c) local += hist[c];
-    int incl = local;
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    if (lane == 63) wsum[wave] = incl;
+    for (int c = c0 + lane; c < c1; c += 64) local += hist[c];
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if (lane == 0) wsum[wave] = local;
     __syncthreads();
-    int before = incl - local;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
-    for (int c = c0; c < c1; ++c) { const int v = hist[c]; start[c] = before; cursor[c] = before; before += v; }
-    if (tid == 1023) start[cnt] = before;  // (the last thread's running sum ends at the total: empty runs add nothing)
+    int carry = 0;
+    for (int w = 0; w < wave; ++w) carry += wsum[w];
+    for (int c = c0; c < c1; c += 64) {
+        const int v = (c + lane < c1) ? hist[c + lane] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (c + lane < c1) { start[c + lane] = carry + incl - v; cursor[c + lane] = carry + incl - v; }
+        carry += __shfl(incl, 63);
+    }
+    if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; start[cnt] = tot; }
 }
 
 __global__ __launch_bounds__(256) void k_sort_scatter(const double *__restrict__ key, int64_t n, const SortInfo *__restrict__ info, int32_t *__restrict__ cursor,
@@ -236,41 +242,48 @@ __global__ __launch_bounds__(256) void k_sort_rank(const double *__restrict__ ke
     order[r] = (int32_t)i;
 }
 
-// ---- suppression pairs of the dense merge through a uniform grid (n >= kGridMin, thr > 0): a pair can only overlap if the envelope
-// centres are closer than the largest envelope extent in both axes, so with cells at least that large every partner of a box sits in
-// the 3 x 3 cells around it.  Replaces the all-pairs envelope test (n^2 / 2) of k_nms_mask<EDGES> by ~9 cells x occupancy tests per box;
+// ---- suppression pairs of the dense merge through a uniform grid (n >= kGridMin, thr > 0): two envelopes can only overlap if their
+// centres are closer than the larger of the two extents in both axes, so with cells at least as large as every SMALL box's extent every
+// small partner of a small box sits in the 3 x 3 cells around it.  The cell is min(largest extent, 4 x mean extent) (never below
+// span / 255): boxes larger than the cell ("large", at most a quarter of the rows by Markov, a handful on real maps) stay out of the
+// grid and are tested against every row instead, so a few outsized quads cannot blow the cells up to hundreds of members.  Replaces the all-pairs envelope test (n^2 / 2) of k_nms_mask<EDGES> by ~9 cells x occupancy tests per box;
 // the exact IoU runs on the same candidate set (same class, envelopes not disjoint), so the edge list is the same set of pairs.
 static constexpr int kGridDim = 256;  // cells per axis at most
 static constexpr int64_t kGridMin = 8192;
 
-struct GridInfo { double ox, oy, inv_cell; int gw, gh; };
+struct GridInfo { double ox, oy, inv_cell, small_max; int gw, gh, n_large, pad; };
 
 __global__ __launch_bounds__(1024) void k_grid_info(const BoxMeta *__restrict__ meta, int64_t n, GridInfo *__restrict__ info) {
-    __shared__ double s0[1024], s1[1024], s2[1024], s3[1024], s4[1024];
-    double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY, ext = 0.0;
+    __shared__ double s0[1024], s1[1024], s2[1024], s3[1024], s4[1024], s5[1024], s6[1024];
+    double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY, ext = 0.0, esum = 0.0, ecnt = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const BoxMeta m = meta[i];
         if (!(m.x0 <= m.x1)) continue;  // invalid quad: empty envelope, never a partner
         x0 = fmin(x0, m.x0); y0 = fmin(y0, m.y0); x1 = fmax(x1, m.x1); y1 = fmax(y1, m.y1);
-        ext = fmax(ext, fmax(m.x1 - m.x0, m.y1 - m.y0));
+        const double e = fmax(m.x1 - m.x0, m.y1 - m.y0);
+        ext = fmax(ext, e); esum += e; ecnt += 1.0;
     }
     s0[threadIdx.x] = x0; s1[threadIdx.x] = y0; s2[threadIdx.x] = x1; s3[threadIdx.x] = y1; s4[threadIdx.x] = ext;
+    s5[threadIdx.x] = esum; s6[threadIdx.x] = ecnt;
     __syncthreads();
     for (int d = 512; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) {
             s0[threadIdx.x] = fmin(s0[threadIdx.x], s0[threadIdx.x + d]); s1[threadIdx.x] = fmin(s1[threadIdx.x], s1[threadIdx.x + d]);
             s2[threadIdx.x] = fmax(s2[threadIdx.x], s2[threadIdx.x + d]); s3[threadIdx.x] = fmax(s3[threadIdx.x], s3[threadIdx.x + d]);
             s4[threadIdx.x] = fmax(s4[threadIdx.x], s4[threadIdx.x + d]);
+            s5[threadIdx.x] += s5[threadIdx.x + d]; s6[threadIdx.x] += s6[threadIdx.x + d];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         GridInfo g;
+        g.n_large = 0; g.pad = 0; g.small_max = 0.0;
         if (!(s0[0] <= s2[0])) { g.ox = g.oy = 0.0; g.inv_cell = 0.0; g.gw = g.gh = 1; }
         else {
             const double wx = s2[0] - s0[0], wy = s3[0] - s1[0];
-            double cell = fmax(s4[0], fmax(wx, wy) / (double)(kGridDim - 1));
-            cell = cell > 0.0 ? cell * (1.0 + 1e-9) : 1.0;  // (a hair larger than the largest extent: centre distance < cell for overlapping envelopes)
+            double cell = fmax(fmin(s4[0], 4.0 * s5[0] / s6[0]), fmax(wx, wy) / (double)(kGridDim - 1));
+            g.small_max = cell;  // rows with a larger extent are "large"
+            cell = cell > 0.0 ? cell * (1.0 + 1e-9) : 1.0;  // (a hair larger than the largest small extent: centre distance < cell for overlapping small envelopes)
             g.ox = s0[0]; g.oy = s1[0]; g.inv_cell = 1.0 / cell;
             g.gw = min(kGridDim, (int)(wx / cell) + 1); g.gh = min(kGridDim, (int)(wy / cell) + 1);
         }
@@ -284,11 +297,15 @@ __device__ __forceinline__ int grid_cell(const BoxMeta &m, const GridInfo &g, in
     return cy * g.gw + cx;
 }
 
-__global__ __launch_bounds__(256) void k_grid_count(const BoxMeta *__restrict__ meta, int64_t n, const GridInfo *__restrict__ info, int32_t *__restrict__ hist) {
+__device__ __forceinline__ bool grid_is_large(const BoxMeta &m, const GridInfo &g) { return fmax(m.x1 - m.x0, m.y1 - m.y0) > g.small_max; }
+
+__global__ __launch_bounds__(256) void k_grid_count(const BoxMeta *__restrict__ meta, int64_t n, GridInfo *__restrict__ info, int32_t *__restrict__ hist,
+                                                   int32_t *__restrict__ large) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const BoxMeta m = meta[i];
     if (!(m.x0 <= m.x1)) return;
+    if (grid_is_large(m, *info)) { large[atomicAdd(&info->n_large, 1)] = (int32_t)i; return; }
     int cx, cy;
     atomicAdd(&hist[grid_cell(m, *info, cx, cy)], 1);
 }
@@ -298,40 +315,83 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const BoxMeta *__restrict_
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const BoxMeta m = meta[i];
-    if (!(m.x0 <= m.x1)) return;
+    if (!(m.x0 <= m.x1) || grid_is_large(m, *info)) return;
     int cx, cy;
     members[atomicAdd(&cursor[grid_cell(m, *info, cx, cy)], 1)] = (int32_t)i;
 }
 
-// thread = box j (sorted position): partners i < j in the 3 x 3 cells around it -> edge (i, j) when same class and IoU(i, j) >= thr
+// thread = box j (sorted position).  Small j: small partners i < j in the 3 x 3 cells around it.  Every j: the large rows (a small j takes
+// each large row, a large j the large rows before it, so every pair with a large member is seen once).  Two phases per round, as in
+// k_nms_mask: every lane runs up to kGridRound cheap class + envelope tests of its row and queues the survivors in LDS; then the whole
+// workgroup clips the queued pairs, one per lane (the exact IoU is ~100x a cheap test and would otherwise run in one lane of a wave).
+// Edge (lo, hi) when IoU(lo, hi) >= thr, the earlier row always the first operand (as k_nms_mask evaluates it).
+static constexpr int kGridRound = 16;
 __global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ sboxes, const int32_t *__restrict__ scls, const BoxMeta *__restrict__ meta, int64_t n,
                                                    double thr, const GridInfo *__restrict__ info, const int32_t *__restrict__ start,
-                                                   const int32_t *__restrict__ members, unsigned long long *__restrict__ edges,
-                                                   unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
+                                                   const int32_t *__restrict__ members, const int32_t *__restrict__ large,
+                                                   unsigned long long *__restrict__ edges, unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
+    __shared__ unsigned long long queue[256 * kGridRound];
+    __shared__ int qn;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const BoxMeta mj = meta[j];
-    if (!(mj.x0 <= mj.x1)) return;
     const GridInfo g = *info;
-    int cx, cy;
-    grid_cell(mj, g, cx, cy);
-    const int cj = scls[j];
-    P2 q[4];
-    for (int k = 0; k < 4; ++k) { q[k].x = sboxes[j * 8 + 2 * k]; q[k].y = sboxes[j * 8 + 2 * k + 1]; }
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.gh - 1); ++yy)
-        for (int xx = max(cx - 1, 0); xx <= min(cx + 1, g.gw - 1); ++xx) {
-            const int c = yy * g.gw + xx;
-            for (int m = start[c]; m < start[c + 1]; ++m) {
-                const int i = members[m];
-                if (i >= j || scls[i] != cj || !meta_overlap(meta[i], mj)) continue;
-                P2 p[4];
-                for (int k = 0; k < 4; ++k) { p[k].x = sboxes[(int64_t)i * 8 + 2 * k]; p[k].y = sboxes[(int64_t)i * 8 + 2 * k + 1]; }
-                if (poly_iou_core(p, q) >= thr) {  // (row box first, as k_nms_mask evaluates it)
-                    const unsigned int e = atomicAdd(edge_count, 1u);
-                    if (e < edge_cap) edges[e] = ((unsigned long long)i << 32) | (unsigned long long)j;
-                }
+    BoxMeta mj;
+    mj.x0 = 1.0; mj.x1 = -1.0; mj.y0 = mj.y1 = 0.0;
+    int cj = -1;
+    if (j < n) { mj = meta[j]; cj = scls[j]; }
+    const bool valid = mj.x0 <= mj.x1;
+    const bool j_large = valid && grid_is_large(mj, g);
+    int cx = 0, cy = 0;
+    if (valid) grid_cell(mj, g, cx, cy);
+    int ph = !valid ? 10 : (j_large ? 9 : 0), cur = 0, end = 0;
+    const int32_t *src = members;
+    bool in_large = false;
+    auto advance = [&]() -> bool {  // true when src[cur] is the next candidate
+        while (cur >= end) {
+            if (ph >= 10) return false;
+            if (ph < 9) {
+                const int yy = cy - 1 + ph / 3, xx = cx - 1 + ph % 3;
+                ++ph;
+                if (yy < 0 || yy >= g.gh || xx < 0 || xx >= g.gw) continue;
+                const int c = yy * g.gw + xx;
+                cur = start[c]; end = start[c + 1];
+            } else { ph = 10; cur = 0; end = g.n_large; src = large; in_large = true; }
+        }
+        return true;
+    };
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    for (;;) {
+        int tests = 0;
+        while (tests < kGridRound && advance()) {
+            const int i = src[cur++];
+            ++tests;
+            const bool take = in_large ? (i != (int)j && (!j_large || i < (int)j)) : i < (int)j;
+            if (take && scls[i] == cj && meta_overlap(meta[i], mj)) {
+                const unsigned long long lo = i < (int)j ? (unsigned long long)i : (unsigned long long)j, hi = i < (int)j ? (unsigned long long)j : (unsigned long long)i;
+                queue[atomicAdd(&qn, 1)] = (lo << 32) | hi;
             }
         }
+        const int more = advance() ? 1 : 0;
+        __syncthreads();
+        const int nq = qn;
+        for (int e = threadIdx.x; e < nq; e += 256) {
+            const unsigned long long pr = queue[e];
+            const int64_t lo = (int64_t)(pr >> 32), hi = (int64_t)(pr & 0xffffffffull);
+            P2 p[4], q[4];
+            for (int k = 0; k < 4; ++k) {
+                p[k].x = sboxes[lo * 8 + 2 * k]; p[k].y = sboxes[lo * 8 + 2 * k + 1];
+                q[k].x = sboxes[hi * 8 + 2 * k]; q[k].y = sboxes[hi * 8 + 2 * k + 1];
+            }
+            if (poly_iou_core(p, q) >= thr) {
+                const unsigned int slot = atomicAdd(edge_count, 1u);
+                if (slot < edge_cap) edges[slot] = pr;
+            }
+        }
+        const int any = __syncthreads_or(more);
+        if (threadIdx.x == 0) qn = 0;
+        if (!any) break;
+        __syncthreads();
+    }
 }
 
 // One wave per 64x64 block of the (row i, col j>i) pair matrix.  Phase 1: every lane runs the 64 cheap
@@ -525,7 +585,7 @@ static constexpr int kSegPairCap = 12288;
 __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
                                                         const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
                                                         double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
-                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status) {
+                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto) {
     __shared__ double skey[kSegMax];
     __shared__ int32_t sord[kSegMax];
     __shared__ int32_t scl[kSegMax];
@@ -537,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restric
     int seg = blockIdx.x;
     int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
     int n = s1 - s0;
-    if (n <= 0) { if (threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }
+    if (n <= skip_upto) { if (n <= 0 && skip_upto == 0 && threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }  // (short ones: k_merge_segments_wave)
     if (n > kSegMax) {  // caller promised segments <= kSegMax; flag and leave outputs untouched
         if (threadIdx.x == 0) atomicExch(status, 1);
         return;
@@ -623,6 +683,77 @@ __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restric
         }
         if (lane == 0 && n_keep) n_keep[seg] = kept;
     }
+}
+
+// Segments of at most 64 rows (the usual tile: a dozen symbols): one wave per segment, a few KB of LDS, so a CU holds dozens of
+// segments at once instead of one 1024-thread workgroup each.  Same phases and the same arithmetic as k_merge_segments.
+static constexpr int kSegWave = 64;
+__global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                           const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
+                                                           double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
+                                                           int32_t *__restrict__ n_keep) {
+    __shared__ double skey[kSegWave];
+    __shared__ int32_t sord[kSegWave];
+    __shared__ int32_t scl[kSegWave];
+    __shared__ BoxMeta smeta[kSegWave];
+    __shared__ double sbox[kSegWave * 8];
+    __shared__ unsigned long long sbits[kSegWave];
+    __shared__ unsigned short spairs[kSegWave * (kSegWave - 1) / 2];
+    __shared__ unsigned int npairs_s;
+    const int seg = blockIdx.x, t = threadIdx.x;
+    const int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    const int n = s1 - s0;
+    if (n <= 0) { if (t == 0 && n_keep) n_keep[seg] = 0; return; }
+    if (n > kSegWave) return;  // k_merge_segments takes it
+    if (t == 0) npairs_s = 0;
+    if (t < n) skey[t] = sort_key(conf[s0 + t]);
+    sbits[t] = 0ull;
+    __syncthreads();
+    if (t < n) {
+        const double ki = skey[t];
+        int rank = 0;
+        for (int u = 0; u < n; ++u) rank += (skey[u] > ki) | ((skey[u] == ki) & (u < t));
+        sord[rank] = t;
+    }
+    __syncthreads();
+    if (t < n) {
+        const int src = s0 + sord[t];
+        order[s0 + t] = src;
+        P2 p[4];
+        for (int k = 0; k < 4; ++k) { p[k].x = boxes[(int64_t)src * 8 + 2 * k]; p[k].y = boxes[(int64_t)src * 8 + 2 * k + 1]; }
+        for (int k = 0; k < 4; ++k) { sbox[t * 8 + 2 * k] = p[k].x; sbox[t * 8 + 2 * k + 1] = p[k].y; }
+        BoxMeta m;
+        if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+        else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
+        smeta[t] = m;
+        scl[t] = cls[src];
+    }
+    __syncthreads();
+    const bool all_hit = !(thr > 0.0);
+    // cheap tests: lane = column j against the rows i < j (the row data are LDS broadcasts)
+    if (t < n) {
+        const BoxMeta mj = smeta[t];
+        const int cj = scl[t];
+        for (int i = 0; i < t; ++i) {
+            if (scl[i] != cj) continue;
+            if (all_hit) atomicOr(&sbits[i], 1ull << t);
+            else if (meta_overlap(smeta[i], mj)) spairs[atomicAdd(&npairs_s, 1u)] = (unsigned short)((i << 8) | t);
+        }
+    }
+    __syncthreads();
+    const int npairs = (int)npairs_s;
+    for (int e = t; e < npairs; e += 64) {
+        const int i = spairs[e] >> 8, j = spairs[e] & 0xff;
+        P2 p[4], q[4];
+        for (int k = 0; k < 4; ++k) { p[k].x = sbox[i * 8 + 2 * k]; p[k].y = sbox[i * 8 + 2 * k + 1]; q[k].x = sbox[j * 8 + 2 * k]; q[k].y = sbox[j * 8 + 2 * k + 1]; }
+        if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i], 1ull << j);
+    }
+    __syncthreads();
+    unsigned long long rem = 0ull;  // wave-uniform greedy scan
+    for (int i = 0; i < n; ++i)
+        if (!((rem >> i) & 1ull)) rem |= sbits[i];
+    if (t < n) keep[s0 + t] = (uint8_t)(!((rem >> t) & 1ull));
+    if (t == 0 && n_keep) n_keep[seg] = n - __popcll(rem & (n == 64 ? ~0ull : ((1ull << n) - 1ull)));
 }
 
 // ------------------------------------------------------------------------------------------------ consensus (single workgroup)
@@ -1013,8 +1144,10 @@ int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, co
     int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
     if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
     OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, thr,
-                       order, keep, (int32_t *)nullptr, status);
+    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, thr, order, keep, (int32_t *)nullptr);
+    if (n > kSegWave)  // (some segment may be longer than a wave takes)
+        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, thr,
+                           order, keep, (int32_t *)nullptr, status, kSegWave);
     OBB_LAUNCH_CHECK(ctx);
     if (n <= kSegMax) return OBB_OK;  // no segment can be longer than the LDS-resident kernel takes
     // Segments above kSegMax rows were flagged and left untouched by the kernel (a tile with more than 512 detections: max_det > 512, or
@@ -1056,7 +1189,7 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         int32_t h[2] = {0, (int32_t)n};
         OBB_HIP(ctx, hipMemcpyAsync(segoff, h, sizeof h, hipMemcpyHostToDevice, st));
         OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status);
+        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status, 0);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }
@@ -1081,17 +1214,17 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         OBB_HIP(ctx, hipMemsetAsync(ecount, 0, sizeof(unsigned int), st));
         if (n >= kGridMin) {  // candidate partners through a uniform grid instead of all pairs
             const int ncell = kGridDim * kGridDim;
-            int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * ((size_t)n + 2 * (size_t)ncell + 64));
+            int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * (2 * (size_t)n + 2 * (size_t)ncell + 64));
             if (!gbuf) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
-            int32_t *hist = gbuf, *start = gbuf + ncell + 8, *members = gbuf + 2 * ncell + 32;
+            int32_t *hist = gbuf, *start = gbuf + ncell + 8, *members = gbuf + 2 * ncell + 32, *large = members + n;
             GridInfo *ginfo = (GridInfo *)(gbuf + 2 * ncell + 16);
             OBB_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int32_t) * ncell, st));
             hipLaunchKernelGGL(k_grid_info, dim3(1), dim3(1024), 0, st, (const BoxMeta *)meta, n, ginfo);
-            hipLaunchKernelGGL(k_grid_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist);
+            hipLaunchKernelGGL(k_grid_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, ginfo, hist, large);
             hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, ncell, start, hist);
             hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist, members);
             hipLaunchKernelGGL(k_grid_pairs, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const double *)sboxes, (const int32_t *)scls, (const BoxMeta *)meta, n,
-                               thr, (const GridInfo *)ginfo, (const int32_t *)start, (const int32_t *)members, edges, ecount, cap);
+                               thr, (const GridInfo *)ginfo, (const int32_t *)start, (const int32_t *)members, (const int32_t *)large, edges, ecount, cap);
         } else {
             hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,
                                (const BoxMeta *)meta, n, thr, (unsigned long long *)nullptr, edges, ecount, cap);

@@ -121,11 +121,16 @@ def test_merge_idempotent_at_scale(ops):
     srt = S[order.long()].cpu().numpy()
     assert np.all(np.diff(srt) <= 0)
     # the grid-binned pair search (n >= 8192) against the all-pairs bit matrix on the same sorted boxes: identical keep flags; also
-    # with one box as large as the whole map (the grid degenerates to a few huge cells)
-    for huge in (False, True):
+    # with one box as large as the whole map, and with 5 % of the rows 20x enlarged (rows above the cell size stay out of the grid and
+    # are tested against every row)
+    for huge in (0, 1, 2):
         bb = boxes.copy()
-        if huge:
+        if huge == 1:
             bb[17] = [0, 0, 8192, 0, 8192, 8192, 0, 8192]
+        if huge == 2:
+            pick = np.random.default_rng(9).permutation(n)[: n // 20]
+            ctr = bb[pick].reshape(-1, 4, 2).mean(1, keepdims=True)
+            bb[pick] = ((bb[pick].reshape(-1, 4, 2) - ctr) * 20.0 + ctr).reshape(-1, 8)
         Bh = dev(bb, torch.float64)
         order, keep, nk = ops.merge_detections(Bh, Cc, S, 0.4)
         sb, sc = Bh[order.long()].contiguous(), Cc[order.long()].contiguous()

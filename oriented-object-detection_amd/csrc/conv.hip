@@ -570,6 +570,241 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
     STAMP_FLUSH
 }
 
+// ------------------------------------------------------------------------------------------------ weights-resident 3x3, two half-groups
+//
+// k_conv3_pair: 3x3 stride-1 layers with 64 input channels and 64-cout groups on 13 x 13 tiles (the P3/P4/P5 box-branch convs of the head).
+// What bounds k_conv_igemm on these layers is the CU's load path, not HBM and not the matrix pipe: every 169-pixel tile re-fetches its
+// group's 72 KiB of weights from L2 (in 16-channel stages) next to 28 KiB of activations, and a CU sustains only ~10-30 B/clk from L2.
+// Keeping the weights resident needs 72 KiB + one 32 KiB input tile per group, i.e. one 4-wave group per CU, whose staging, barriers and
+// epilogue then run with the matrix pipe idle (measured: no gain).  Here ONE 512-thread workgroup per CU shares the resident weights
+// between two 4-wave halves that walk alternate tiles one phase apart: while one half runs its 216-MFMA k loop the other stores its
+// previous tile, copies the next input tile from registers to LDS and issues the loads of the tile after (two phases = a whole tile
+// ahead).  One barrier per phase; loads and stores stay in flight across it (raw s_barrier, LDS counter only).
+//   TAIL = 4: the layer is followed by the head's plain 1x1 (64 -> <= 64 fp32 rows).  With the cout order chosen below a lane's two packed
+//   8-channel output pieces of a pixel are exactly its two B-operand fragments of that second GEMM (natural k order), so the tail runs
+//   straight from registers and the intermediate never touches LDS.
+template <bool F16, int TAIL>
+__global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
+    typedef typename HX<F16>::vec8 hx8;
+    constexpr int MF = 3, NF = 4, PST = 144, KST = 18, T = 13, TWIN = T + 2, IN_PX = TWIN * TWIN, NCHUNK = IN_PX * 8, MAXLD = 8;
+    static_assert(NCHUNK <= MAXLD * 256, "staging plan");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float s_bias[16 * NF];
+    __shared__ __attribute__((aligned(16))) float s_bias2[TAIL > 0 ? 16 * TAIL : 4];
+    const int tid = threadIdx.x, lane = tid & 63, htid = tid & 255;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wave8 >> 2, hw = wave8 & 3;  // half-group, wave inside it
+    const int g = lane >> 4, pl = lane & 15;
+    const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+    const int cb = lin % P.ncb;
+    const int bx = (lin / P.ncb) * 8 + xcd;
+    if (bx >= P.gx) return;
+    char *abuf = smem + h * P.act_bytes;
+    char *wlds = smem + 2 * P.act_bytes;
+    char *w2lds = wlds + KST * NF * 1024;
+    if (tid < 16 * NF) s_bias[tid] = P.bias[cb * 16 * NF + tid];
+    if constexpr (TAIL > 0) {
+        if (tid < 16 * TAIL) s_bias2[tid] = P.bias2[tid];
+        // tail weights (2 k-steps x TAIL fragments), rows re-ordered to the natural cout order (fragment f, row r -> cout f*16 + r): a store
+        // instruction of the fp32 rows then covers 64 contiguous bytes per pixel (4 lanes x float4) instead of four 16-B pieces 64 B apart
+        for (int i = tid; i < 2 * TAIL * 64; i += 512) {
+            const int l = i & 63, f = (i >> 6) % TAIL, ks = i / (64 * TAIL);
+            const int r = l & 15, gq = l >> 4;
+            *reinterpret_cast<u32x4 *>(w2lds + i * 16) = reinterpret_cast<const u32x4 *>(P.w2pk)[((ks * TAIL + (r >> 2)) * 64) + (f * 4 + (r & 3)) + 16 * gq];
+        }
+    }
+    const int t0 = bx * P.tpw, t1 = min(t0 + P.tpw, P.ntiles);
+    if (t0 >= t1) return;
+    const int n_h = (t1 - t0 - h + 1) >> 1;            // tiles of this half: t0 + h, t0 + h + 2, ...
+    const int np = max(1 + 2 * ((t1 - t0 + 1) >> 1), 2 + 2 * ((t1 - t0) >> 1));  // phases until both halves are done
+
+    int pixb[MF], ptyx[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int p = (hw * MF + mf) * 16 + pl;
+        const int ty = p / T, tx = p - ty * T;
+        const bool ok = p < T * T;
+        pixb[mf] = (ok ? (ty * TWIN + tx) * PST : 0) + g * 16;
+        ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
+    }
+    int ipos[MAXLD];
+#pragma unroll
+    for (int k = 0; k < MAXLD; ++k) {
+        const int idx = htid + k * 256, pix = idx >> 3;
+        const int iy = pix / TWIN, ix = pix - iy * TWIN;
+        ipos[k] = idx < NCHUNK ? ((iy << 16) | ix) : -1;
+    }
+    auto tile_origin = [&](int t, int &b, int &oy0, int &ox0) {
+        const int tx_i = t % P.tiles_x, r = t / P.tiles_x;
+        const int ty_i = r % P.tiles_y;
+        b = r / P.tiles_y;
+        oy0 = ty_i * T; ox0 = tx_i * T;
+    };
+    constexpr unsigned NOPIX = 0xffffffffu;
+    u32x4 pre[MAXLD];
+    auto fetch_tile = [&](int t) {  // global -> registers, one whole input tile (zero padding through the descriptor's range check)
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        const bf16_t *base = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)P.in_span_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            const int gy = oy0 - 1 + (ipos[k] >> 16), gx = ox0 - 1 + (ipos[k] & 0xffff);
+            const bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+            const int cc = (htid + k * 256) & 7;
+            const unsigned off = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u : NOPIX;
+            pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {  // registers -> this half's LDS tile
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            const int idx = htid + k * 256;
+            if (idx < NCHUNK) *reinterpret_cast<u32x4 *>(abuf + (idx >> 3) * PST + (idx & 7) * 16) = pre[k];
+        }
+    };
+    if (n_h > 0) fetch_tile(t0 + h);
+    {   // the resident weight block of this cout group, rows re-ordered so that value (f, i) of lane group g is cout
+        // (f >> 1) * 32 + g * 8 + (f & 1) * 4 + i: a lane's two 16-B output pieces then sit 64 B apart and the four lanes of a pixel write
+        // 64 contiguous bytes per store instruction; the same order is the natural k order of the tail's B operand
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(P.wpk) + (size_t)cb * (KST * NF * 64);
+        for (int i = tid; i < KST * NF * 64; i += 512) {
+            const int l = i & 63, f = (i >> 6) & 3, ks = i >> 8;
+            const int r = l & 15, gq = l >> 4, gg = r >> 2, ii = r & 3;
+            const int fs = (gg & 1) * 2 + (f & 1), rs = ((f >> 1) * 2 + (gg >> 1)) * 4 + ii;
+            *reinterpret_cast<u32x4 *>(wlds + i * 16) = wsrc[((ks * NF + fs) * 64) + rs + 16 * gq];
+        }
+    }
+    const bool do_act = P.act != 0;
+    const int cbase = cb * 16 * NF + g * 4 * NF;
+    f32x4 acc[MF][NF];
+
+    auto kloop = [&]() {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k step ks = tap ks/2, channels (ks & 1) * 32 + g * 8 .. + 7: the tap offset is a constant of the unrolled step
+        auto ld = [&](int ks, hx8 (&w)[NF], hx8 (&a)[MF]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) w[f] = *reinterpret_cast<const hx8 *>(wlds + ((ks * NF + f) * 64 + lane) * 16);
+            const int tap = ks >> 1, dy = tap / 3, dx = tap - dy * 3;
+            const int off = (dy * TWIN + dx) * PST + (ks & 1) * 64;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) a[mf] = *reinterpret_cast<const hx8 *>(abuf + pixb[mf] + off);
+        };
+        auto step = [&](const hx8 (&w)[NF], const hx8 (&a)[MF]) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[mf][f] = HX<F16>::mfma(w[f], a[mf], acc[mf][f]);
+        };
+        hx8 wA[NF], aA[MF], wB[NF], aB[MF];
+        ld(0, wA, aA);
+#pragma unroll
+        for (int ks = 0; ks < KST; ks += 2) {
+            ld(ks + 1, wB, aB);
+            __builtin_amdgcn_sched_barrier(0);
+            step(wA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < KST) ld(ks + 2, wA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            step(wB, aB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto epilogue = [&](int t) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        float bias[NF * 4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float4 bv = *reinterpret_cast<const float4 *>(s_bias + (f >> 1) * 32 + g * 8 + (f & 1) * 4);
+            bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
+        }
+        hx8 w2[TAIL > 0 ? 2 * TAIL : 1];
+        if constexpr (TAIL > 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * TAIL; ++i) w2[i] = *reinterpret_cast<const hx8 *>(w2lds + (i * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
+            const bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout);
+            const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
+            float v[NF * 4];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r] + bias[f * 4 + r];
+            if (do_act) {
+#pragma unroll
+                for (int c = 0; c < NF * 4; ++c) v[c] = silu_f(v[c]);
+            }
+            uint4 o[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                o[hh].x = HX<F16>::pack2(v[hh * 8 + 0], v[hh * 8 + 1]); o[hh].y = HX<F16>::pack2(v[hh * 8 + 2], v[hh * 8 + 3]);
+                o[hh].z = HX<F16>::pack2(v[hh * 8 + 4], v[hh * 8 + 5]); o[hh].w = HX<F16>::pack2(v[hh * 8 + 6], v[hh * 8 + 7]);
+            }
+            if constexpr (TAIL == 0) {
+                if (ok) {
+                    bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int occ = cb * 2 * NF + hh * 4 + g;  // 8-channel chunk index inside the output slice
+                        if (occ * 8 + 8 <= P.cout) *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = o[hh];
+                    }
+                }
+            } else {
+                f32x4 acc2[TAIL];
+#pragma unroll
+                for (int f = 0; f < TAIL; ++f) acc2[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    hx8 a2;
+                    __builtin_memcpy(&a2, &o[ks], 16);
+#pragma unroll
+                    for (int f = 0; f < TAIL; ++f) acc2[f] = HX<F16>::mfma(w2[ks * TAIL + f], a2, acc2[f]);
+                }
+                if (ok) {  // (2-D launch, 16-B aligned fp32 rows, cout2 a multiple of 4: checked by the host)
+                    float *op = P.out2 + (int64_t)b * P.out2_bs + opix * P.out2_cs + P.out2_co + g * 4;
+#pragma unroll
+                    for (int f = 0; f < TAIL; ++f) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(s_bias2 + f * 16 + g * 4);
+                        if (f * 16 + g * 4 + 4 <= P.cout2)
+                            *reinterpret_cast<float4 *>(op + f * 16) = make_float4(acc2[f][0] + bv.x, acc2[f][1] + bv.y, acc2[f][2] + bv.z, acc2[f][3] + bv.w);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // phase q of a half (q = p - h): 0 = stage tile 0; odd = k loop of tile q/2; even = store tile q/2 - 1, stage tile q/2, fetch tile q/2 + 1
+    STAMP_INIT  // (diagnostic build: 0 barrier wait, 1 epilogue, 2 tile copy to LDS incl. the wait for its loads, 3 k loop, 4 fetch issue)
+    for (int p = 0; p < np; ++p) {
+        const int q = p - h;
+        if (q >= 0) {
+            const int i = q >> 1;
+            if (q & 1) {
+                if (i < n_h) { kloop(); STAMP(3) STAMP_TILE }
+            } else {
+                if (i >= 1 && i - 1 < n_h) { epilogue(t0 + h + 2 * (i - 1)); STAMP(1) }
+                if (i < n_h) {
+                    store_tile();
+                    STAMP(2)
+                    if (i + 1 < n_h) { fetch_tile(t0 + h + 2 * (i + 1)); STAMP(4) }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        STAMP(0)
+    }
+    STAMP_FLUSH
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
@@ -601,6 +836,9 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) 
     //  group per CU) gained nothing -- 112.6 -> 115.7 us -- so they keep the 16-channel stages: their k loop is bound by LDS operand
     //  reads, 7 KiB per 12 MFMAs and wave, not by the per-stage global-memory latency)
     if (stride == 1 && t.MF == 3 && (cin == 32 || cin == 64) && (t.NF == 2 || t.NF == 1)) t.CK = cin;
+    // 64 -> 64-cout groups: the same single-stage packing, run by k_conv3_pair (two half-groups per CU sharing the resident weights)
+    static const int pair_on = getenv("OBB_PAIR") ? atoi(getenv("OBB_PAIR")) : 1;
+    if (pair_on && stride == 1 && t.MF == 3 && cin == 64 && t.NF == 4) t.CK = 64;
     return t;
 }
 
@@ -636,6 +874,14 @@ std::vector<bf16_t> pack_conv_weights(const float *w, int cout, int cin, int ks,
 
 static bool conv_multi_stage(const ConvLaunch &L) { return (L.in_u8 ? 8 : L.cin) > L.CK; }
 static bool conv_wres(const ConvLaunch &L) { return L.ks == 3 && L.CK > 16; }
+static int tail_nf(int cout2);
+// k_conv3_pair's shapes (plan_conv gives them CK = 64): everything else with CK = 64 stays on the one-group WRES form of k_conv_igemm
+static bool conv_pair(const ConvLaunch &L) {
+    return L.ks == 3 && L.stride == 1 && L.MF == 3 && L.NF == 4 && L.CK == 64 && L.cin == 64 && L.TH == 13 && L.TW == 13 && !L.in_u8 && !L.out_f32 &&
+           !L.res.p && L.up_c == 0 && L.cout % 64 == 0 &&
+           (L.tail_cout == 0 || (!L.tail_act16 && tail_nf(L.tail_cout) == 4 && L.cout == 64 && L.tail_cout % 4 == 0 && L.tail_out_hw == 0 &&
+                                 ((L.tail_out.cs | L.tail_out.co) & 3) == 0));
+}
 
 // LDS layout: [input tile (one channel stage) | weights of the stage].  The epilogue's output staging starts at offset 0; for
 // multi-stage layers it may run over the weights as well (they are re-staged at every stage anyway), single-stage layers keep
@@ -756,6 +1002,10 @@ hipError_t launch_conv(const ConvLaunch &L, hipStream_t st) {
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, sd, 64, hipMemcpyDeviceToHost);
         const double n = h[5] ? (double)h[5] : 1.0;
+        if (conv_pair(L))
+            fprintf(stderr, "STAMPS pair k%d s%d cin%d cout%d out%dx%d tail%d | per wave-tile cycles: barrier %.0f  epilogue %.0f  lds_copy %.0f  kloop %.0f  fetch_issue %.0f  (wave-tiles %.0f)\n",
+                    L.ks, L.stride, L.cin, L.cout, L.Hout, L.Wout, L.tail_cout, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n);
+        else
         fprintf(stderr, "STAMPS k%d s%d cin%d cout%d out%dx%d CK%d MF%d NF%d tail%d | per wave-tile cycles: barrier %.0f  lds_stage %.0f  prefetch %.0f  kloop %.0f  epilogue %.0f  (wave-tiles %.0f)\n",
                 L.ks, L.stride, L.cin, L.cout, L.Hout, L.Wout, L.CK, L.MF, L.NF, L.tail_cout, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n);
     }
@@ -860,6 +1110,26 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     int64_t ntiles = (int64_t)L.B * L.tiles_y * L.tiles_x;
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
+    if (conv_pair(L)) {  // one 512-thread workgroup per CU, its two halves walking alternate tiles
+        const int64_t groups = std::max<int64_t>(1, 256 / ncb);
+        P.tpw = (int)std::max<int64_t>(2, (ntiles + groups - 1) / groups);
+        P.gx = (int)((ntiles + P.tpw - 1) / P.tpw); P.ncb = ncb;
+        const size_t lds = 2 * (size_t)P.act_bytes + (size_t)P.kst * L.NF * 1024 + (L.tail_cout > 0 ? 2 * 4 * 1024 : 0);
+        if (P.kst != 18 || P.nstage != 1 || lds > 152 * 1024) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)((P.gx + 7) / 8 * 8 * ncb));
+        auto go = [&](auto kernel) -> hipError_t {
+            static std::vector<const void *> attr_set;  // (the four instantiations share one function-pointer type: keyed by address)
+            if (std::find(attr_set.begin(), attr_set.end(), (const void *)kernel) == attr_set.end()) {
+                hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                if (e != hipSuccess) return e;
+                attr_set.push_back((const void *)kernel);
+            }
+            hipLaunchKernelGGL(kernel, grid, dim3(512), lds, st, P);
+            return hipGetLastError();
+        };
+        if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 4>) : go(k_conv3_pair<false, 4>);
+        return L.f16 ? go(k_conv3_pair<true, 0>) : go(k_conv3_pair<false, 0>);
+    }
     // tiles per workgroup: keep >= ~8 groups per CU in flight, walk up to 8 consecutive tiles per group beyond that
     static const int tpw_max = getenv("OBB_TPW") ? atoi(getenv("OBB_TPW")) : 8;
     int64_t tpw = ntiles * ncb / (256 * 8);

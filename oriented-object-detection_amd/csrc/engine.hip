@@ -18,6 +18,7 @@
 #include "ctx.h"
 #include "dwpw.h"
 #include "f32path.h"
+#include "front.h"
 #include "nnops.h"
 #include "stem.h"
 
@@ -45,7 +46,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW };
+enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
 
 struct Op {
     OpType type;
@@ -56,6 +57,7 @@ struct Op {
     ConvLaunch conv;         // OP_CONV
     Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
+    FrontLaunch front;       // OP_FRONT (model.0 + model.1 + model.2.cv1 in one launch)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
     C3kImgLaunch c3kimg;     // OP_C3KIMG (inner C3k of the stride-32 level, one persistent workgroup per image)
     DwPwLaunch dwpw;         // OP_DWPW (depthwise 3x3 -> 1x1 [-> plain 1x1 to the head] over row stripes)
@@ -179,6 +181,7 @@ struct Builder {
     Model &M;
     Plan &P;
     int err = OBB_OK;
+    bool use_front = false;  // model.0 + model.1 + model.2.cv1 run as one launch (front.hip)
 
     int ch(int c) const { return make_divisible(std::min(c, M.max_ch) * (double)M.width, 8); }
     int reps(int n) const { return n > 1 ? std::max((int)std::lround(n * (double)M.depth), 1) : n; }
@@ -249,10 +252,44 @@ struct Builder {
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true);
     }
 
+    // true if model.0 -> model.1 -> model.2.cv1 can run as ONE launch (front.hip): the n-scale widths on tiles whose sides are multiples of 52
+    bool front_ok(int h, int w) {
+        if (M.f32 || !M.o.front || !M.o.stem || !M.tail || !M.o.tail16) return false;
+        const ConvRecord *r0 = rec("model.0"), *r1 = rec("model.1"), *r2 = rec("model.2.cv1");
+        if (!r0 || !r1 || !r2 || err) return false;
+        if (r0->g != 1 || r1->g != 1 || r2->g != 1 || r0->k != 3 || r1->k != 3 || r2->k != 1 || r0->s != 2 || r1->s != 2 || r2->s != 1 || !r0->act || !r1->act || !r2->act) return false;
+        if (r0->c1 != M.ch || r1->c1 != r0->c2 || r2->c1 != r1->c2) return false;
+        return front_supported(M.ch, r0->c2, r1->c2, r2->c2, h, w) && stem_scale_is_exact(M.f16);
+    }
+    void front(Slice out, int h, int w) {
+        const ConvRecord *r0 = rec("model.0"), *r1 = rec("model.1"), *r2 = rec("model.2.cv1");
+        if (!r0 || !r1 || !r2 || err) return;
+        Op op;
+        op.type = OP_FRONT; op.name = "model.0+model.1+model.2.cv1"; op.in = Slice{-1, 0, M.ch}; op.out = out;
+        op.H = h; op.W = w; op.Ho = h / 4; op.Wo = w / 4;
+        FrontLaunch &L = op.front;
+        L.Hin = h; L.Win = w; L.cin = M.ch; L.f16 = M.f16;
+        L.w0 = upload(pack_stem_weights(r0->w, r0->c2, M.ch, M.ch == 3, M.f16));
+        const ConvTiling t1{13, 13, 3, 2, 16}, t2{1, 1, 1, 2, 32};
+        L.w1 = upload(pack_conv_weights(r1->w, r1->c2, r1->c1, 3, t1, nullptr, 0, M.f16));
+        L.w2 = upload(pack_conv_weights(r2->w, r2->c2, r2->c1, 1, t2, nullptr, 0, M.f16));
+        auto up_bias = [&](const ConvRecord *r) {
+            std::vector<float> bb(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r->c2; ++c) bb[c] = r->b[c];
+            return upload(bb);
+        };
+        L.b0 = up_bias(r0); L.b1 = up_bias(r1); L.b2 = up_bias(r2);
+        op.macs = (double)(h / 2) * (w / 2) * r0->c2 * M.ch * 9 + (double)(h / 4) * (w / 4) * ((double)r1->c2 * r1->c1 * 9 + (double)r2->c2 * r2->c1);
+        P.macs_per_img += op.macs;
+        P.ops.push_back(op);
+        P.named["model.2.cv1"] = out;
+    }
+
     void conv(const std::string &name, Slice in, int Hin, int Win, Slice out, Slice res = Slice(), int head_level = -1,
               const int *perm = nullptr, const char *tail_name = nullptr) {
         const ConvRecord *r = rec(name);
         if (!r || err) return;
+        if (use_front && name == "model.1" && tail_name && std::string(tail_name) == "model.2.cv1") { front(out, Hin * 2, Win * 2); return; }
         bool in_u8 = in.buf < 0;
         int cin = in_u8 ? M.ch : in.C;
         if (r->g != 1 || r->c1 != cin || (!tail_name && r->c2 != out.C)) {
@@ -631,13 +668,14 @@ struct Builder {
         Slice x4 = fold ? whole(buf(H8, W8, c512, "x4")) : sub(cat16, c512, c512), x6 = fold ? whole(buf(H16, W16, c512, "x6")) : sub(cat13, c1024, c512);
         Slice x10 = sub(cat22, c512, c1024), x13 = sub(cat19, c256, c512);
 
-        int b0 = buf(H2, W2, c64, "x0");
-        conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
         const bool t1 = tail16_ok("model.1", "model.2.cv1", H2, W2), t3 = tail16_ok("model.3", "model.4.cv1", H4, W4);
+        use_front = t1 && front_ok(h, w);  // model.0 + model.1 + model.2.cv1 as one launch: x0 never exists
+        int b0 = use_front ? -1 : buf(H2, W2, c64, "x0");
+        if (!use_front) conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
         int b1 = t1 ? -1 : buf(H4, W4, c128, "x1");
         if (!t1) conv("model.1", whole(b0), H2, W2, whole(b1));
         int b2 = buf(H4, W4, c256, "x2", false, 16);  // consumed by a 3x3 stride-2 conv in 16-channel stages
-        if (t1) c3k2(2, Slice(), H4, W4, whole(b2), n2, big, 0.25, "model.1", whole(b0), H2, W2);
+        if (t1) c3k2(2, Slice(), H4, W4, whole(b2), n2, big, 0.25, "model.1", use_front ? Slice{-1, 0, c64} : whole(b0), H2, W2);
         else c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
         int b3 = t3 ? -1 : buf(H8, W8, c256, "x3");
         if (!t3) conv("model.3", whole(b2), H4, W4, whole(b3));
@@ -962,6 +1000,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_stem(L, st);
                 break;
             }
+            case OP_FRONT: {
+                FrontLaunch L = op.front;
+                L.B = B; L.in = tiles; L.out = tref(P, op.out, boff);
+                e = launch_front(L, st);
+                break;
+            }
             case OP_ATTN:
                 if (M.f32) { e = launch_attention_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, st); break; }
                 e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, M.o.attn_mfma, st); break;
@@ -1079,7 +1123,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         // "graph", "fwd_split" and "microbatch", which steer how obb_forward issues its launches from the next call on
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
-            {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem},
+            {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front},
             {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
@@ -1216,6 +1260,7 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_STEM:
                 snprintf(line, sizeof line, "stem %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem.cin, op.stem.cout, op.Ho, op.Wo, 4, op.macs);
                 break;
+            case OP_FRONT: snprintf(line, sizeof line, "front %s cin%d out%dx%d macs%.0f\n", op.name.c_str(), op.front.cin, op.Ho, op.Wo, op.macs); break;
             case OP_ATTN: macs = (double)op.nh * ((double)op.N * op.N * op.kd + (double)op.N * op.N * op.hd);
                 snprintf(line, sizeof line, "attn %s N%d nh%d macs%.0f\n", op.name.c_str(), op.N, op.nh, macs); break;
         }

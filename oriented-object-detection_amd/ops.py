@@ -317,7 +317,7 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
 
 PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016, "f32": 32, "fp32": 32}
 # engine switches of obb_set_option (each restores the separate launches of one fused form; used by the A/B parity tests)
-MODEL_OPTIONS = ("fuse", "tail", "tail16", "bneck", "bneck_cv2", "c3kimg", "dwpw", "upfold", "stem", "hmerge", "sppf_fuse", "attn_mfma", "graph")
+MODEL_OPTIONS = ("fuse", "tail", "tail16", "bneck", "bneck_cv2", "c3kimg", "dwpw", "upfold", "stem", "front", "hmerge", "sppf_fuse", "attn_mfma", "graph")
 
 
 def select_model(slot, device=None):

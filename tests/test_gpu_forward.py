@@ -93,6 +93,31 @@ def test_upsample_concat_read_in_place(ops, net_n, h, w, B):
     assert float((got[..., :77] - ref[..., :77]).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("h,w,B,ch", [(416, 416, 3, 3), (832, 416, 1, 3), (416, 416, 2, 4)])
+def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
+    """model.0 + model.1 + model.2.cv1 in one launch (front.hip, tiles whose sides are multiples of 52) against the stem kernel + the fused
+    conv pair: the same k order everywhere; the only difference is the final rounding of x * sigmoid(x) (one step instead of two), so the
+    16-bit activations may differ by one ulp in a small fraction of the elements and the head stays within the fused-form tolerance."""
+    import make_weights
+    blob = open(make_weights.ensure("n", 12, ch, 0), "rb").read()
+    x = torch.as_tensor(np.random.default_rng(7 + h + w).integers(0, 256, (B, h, w, ch), dtype=np.uint8)).cuda()
+    ops.model_load(blob, precision="f16", front=False)
+    assert not any(l.startswith("front") for l in ops.debug_plan(h, w))
+    ref_head = ops.forward(x).clone()
+    ref = ops.debug_activation("model.2.cv1", B, h, w).clone().float()
+    ops.model_load(blob, precision="f16")
+    assert any(l.startswith("front model.0+model.1+model.2.cv1") for l in ops.debug_plan(h, w))
+    got_head = ops.forward(x)
+    got = ops.debug_activation("model.2.cv1", B, h, w).float()
+    torch.cuda.synchronize()
+    d = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device="cuda")) * 2.0 ** -10  # one 16-bit ulp at the value's binade (upper bound)
+    assert bool((d <= ulp).all()), float((d / ulp).max())
+    assert float((d > 0).float().mean()) < 0.01
+    dh = (got_head[..., :65 + 12] - ref_head[..., :65 + 12]).abs()
+    assert float(dh.max()) < 0.5 and float(dh.mean()) < 1e-2, (float(dh.max()), float(dh.mean()))
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
 def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
     """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""
@@ -101,7 +126,9 @@ def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
     #  1-ulp flips, tested below -- both stay off on both sides here)
     ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=False)
     ref = ops.forward(x).clone()
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=True, bneck=False, c3kimg=False)
+    # (front: the one-launch model.0 + model.1 + model.2.cv1 rounds x * sigmoid(x) to 16 bit in one step (v_fma_mixlo_f16) where the separate
+    #  kernels round to fp32 first: 1-ulp flips, tested in test_front_kernel_matches_separate_launches)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=True, bneck=False, c3kimg=False, front=False)
     if (h, w) == (416, 416):
         assert any("+model.23.cv2.0.2" in l for l in ops.debug_plan(h, w))
     got = ops.forward(x)

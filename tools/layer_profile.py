@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "report":
     f = glob.glob(sys.argv[2] + "/*/*_kernel_trace.csv")[0]
     rows = [r for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ker = [r for r in rows if "obb::k_conv" in r["Kernel_Name"] or "k_dwconv3" in r["Kernel_Name"] or "k_maxpool5" in r["Kernel_Name"] or "k_upsample2" in r["Kernel_Name"] or "k_attention" in r["Kernel_Name"] or "k_fused_chain" in r["Kernel_Name"] or "k_stem_conv" in r["Kernel_Name"] or "k_sppf_pools" in r["Kernel_Name"] or "k_bneck_stripe" in r["Kernel_Name"] or "k_c3k_image" in r["Kernel_Name"] or "k_dwpw_stripe" in r["Kernel_Name"] or "_f32" in r["Kernel_Name"]]
+    ker = [r for r in rows if "obb::k_conv" in r["Kernel_Name"] or "k_dwconv3" in r["Kernel_Name"] or "k_maxpool5" in r["Kernel_Name"] or "k_upsample2" in r["Kernel_Name"] or "k_attention" in r["Kernel_Name"] or "k_fused_chain" in r["Kernel_Name"] or "k_stem_conv" in r["Kernel_Name"] or "k_front" in r["Kernel_Name"] or "k_sppf_pools" in r["Kernel_Name"] or "k_bneck_stripe" in r["Kernel_Name"] or "k_c3k_image" in r["Kernel_Name"] or "k_dwpw_stripe" in r["Kernel_Name"] or "_f32" in r["Kernel_Name"]]
     nf = len(ker) // len(ops)
     ker = ker[-len(ops):]  # last forward
     tot = 0

@@ -19,6 +19,7 @@
 #include "front.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "stem.h"
@@ -34,7 +35,20 @@ struct FrontParams {
     const bf16_t *w0, *w1, *w2; const float *b0, *b1, *b2;
     int Hin, Win, Hs, Ws, Ho, Wo;
     int tiles_x, tiles_y, ntiles, tpw;
+    unsigned long long *stamps;  // diagnostic build (-DOBB_STAMPS) only
 };
+
+#ifdef OBB_STAMPS  // s_memtime phase sums per wave (tools/stamp_conv.sh): 0 barrier + raw copy, 1 convert, 2 stem, 3 conv + tail + stores, 4 fetch issue
+#define STAMP_INIT unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_tiles = 0, st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_TILE ++st_tiles;
+#define STAMP_FLUSH if (P.stamps && lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(P.stamps + i_, st_acc[i_]); atomicAdd(P.stamps + 5, st_tiles); }
+#else
+#define STAMP_INIT
+#define STAMP(i)
+#define STAMP_TILE
+#define STAMP_FLUSH
+#endif
 
 constexpr int kT = 13, kSW = 2 * kT + 1, kIW = 2 * kSW + 1, kSP = kSW * kSW, kPST = 48, kCvtPx = kIW + 1, kCvtPitch = kCvtPx * 8 + 16;
 constexpr int kFrontActBytes = (kSP * kPST + 15) / 16 * 16;
@@ -43,7 +57,7 @@ template <int CH, bool F16>
 __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
     typedef typename HX<F16>::vec8 hx8;
     constexpr int MAXC = CH == 3 ? 12 : 15, RAWP = MAXC * 16, NITEM = kIW * MAXC, MAXI = (NITEM + 255) / 256;
-    static_assert(kIW * RAWP <= kFrontActBytes, "the raw bytes share the activation tile's LDS");
+    static_assert(MAXI * 256 * 16 <= kFrontActBytes, "the raw bytes share the activation tile's LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *raw = smem, *act = smem;  // raw is dead once converted; the stem writes the tile over it
     char *cvt = smem + kFrontActBytes;
@@ -80,11 +94,12 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
     int pixb[3], ptyx[3];
 #pragma unroll
     for (int mf = 0; mf < 3; ++mf) {
-        const int p = (wave * 3 + mf) * 16 + pl;
+        // (slots past the 169 pixels repeat pixel 168: same inputs, same value, same address -- the stores stay unconditional, so the
+        //  compiler can count them and the wait for the next tile's prefetched bytes does not drain this tile's stores)
+        const int p = min((wave * 3 + mf) * 16 + pl, kT * kT - 1);
         const int ty = p / kT, tx = p - ty * kT;
-        const bool ok = p < kT * kT;
-        pixb[mf] = ok ? (ty * 2 * kSW + tx * 2) * kPST : 0;
-        ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
+        pixb[mf] = (ty * 2 * kSW + tx * 2) * kPST;
+        ptyx[mf] = (ty << 16) | tx;
     }
     int scvt[2];  // stem k step ks, lane group g: chunk q = ks*4 + g -> row dy = q/2, pixel pair (q&1)
 #pragma unroll
@@ -113,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
         }
     };
     fetch(t0);
+    // first tile: settled before the loop, so that inside the loop the prefetched bytes are always exactly "three stores old" on the in-order
+    // memory counter and the wait for them leaves the previous tile's stores in flight (the compiler merges the loop entry state with the back edge)
+    __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));
+    STAMP_INIT
 
     for (int t = t0; t < t1; ++t) {
         int b, oy0, ox0;
@@ -122,10 +141,10 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
         __syncthreads();  // the previous tile's conv is done with the activation tile
 #pragma unroll
         for (int k = 0; k < MAXI; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < NITEM) *reinterpret_cast<u32x4 *>(raw + idx * 16) = pre[k];  // [row][MAXC chunks]
+            *reinterpret_cast<u32x4 *>(raw + (tid + k * 256) * 16) = pre[k];  // [row][MAXC chunks] (slots past the last row: zeros into unused LDS)
         }
         __syncthreads();
+        STAMP(0)
         // ---- bytes -> 16-bit v/255 (v * (1/255) rounds like v / 255 for every byte: stem_scale_is_exact, checked before this kernel is chosen)
         if constexpr (CH == 3) {
             // four pixels = 12 bytes at any byte phase: four aligned dwords, three v_alignbyte, twelve byte -> float conversions
@@ -175,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
             }
         }
         __syncthreads();
-        if (t + 1 < t1) fetch(t + 1);  // next tile's bytes: under this tile's arithmetic
+        STAMP(1)
+        fetch(min(t + 1, t1 - 1));  // next tile's bytes, under this tile's arithmetic (unconditional: the last tile re-reads its own; keeps the count exact)
+        STAMP(4)
         // ---- stem: 46 fragments of 16 stem pixels, dealt round-robin to the waves (pixel p = j*16 + pl advances by 64 = 2 rows + 10)
         {
             int p = wave * 16 + pl, sy = p / kSW, sx = p - sy * kSW;
@@ -201,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
             }
         }
         __syncthreads();
+        STAMP(2)
         // ---- conv 3x3 s2 (16 -> 32) on the LDS tile
         f32x4 acc[3][2];
 #pragma unroll
@@ -238,13 +260,16 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
                 for (int i = 0; i < 4; ++i) v[f * 4 + i] = silu_f(acc2[f][i] + b2[f * 4 + i]);
             uint4 o;
             o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]); o.z = HX<F16>::pack2(v[4], v[5]); o.w = HX<F16>::pack2(v[6], v[7]);
-            if (ptyx[mf] >= 0) {
+            {
                 const int64_t opix = (int64_t)(oy0 + (ptyx[mf] >> 16)) * P.Wo + ox0 + (ptyx[mf] & 0xffff);
                 bf16_t *op = P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs + (int64_t)(g >> P.out_bsh) * P.out_ps + ((g & P.out_bmask) << 3);
                 *reinterpret_cast<uint4 *>(op) = o;
             }
         }
+        STAMP(3)
+        STAMP_TILE
     }
+    STAMP_FLUSH
 }
 
 bool front_supported(int cin, int c0, int c1, int c2, int Hin, int Win) {
@@ -285,8 +310,25 @@ hipError_t launch_front(const FrontLaunch &L, hipStream_t st) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, P);
         return hipGetLastError();
     };
-    if (L.cin == 3) return L.f16 ? go(k_front<3, true>) : go(k_front<3, false>);
-    return L.f16 ? go(k_front<4, true>) : go(k_front<4, false>);
+    P.stamps = nullptr;
+#ifdef OBB_STAMPS
+    static unsigned long long *stamp_dev = nullptr;
+    if (!stamp_dev) (void)hipMalloc((void **)&stamp_dev, 64);
+    (void)hipMemsetAsync(stamp_dev, 0, 64, st);
+    P.stamps = stamp_dev;
+#endif
+    hipError_t e = L.cin == 3 ? (L.f16 ? go(k_front<3, true>) : go(k_front<3, false>)) : (L.f16 ? go(k_front<4, true>) : go(k_front<4, false>));
+#ifdef OBB_STAMPS
+    if (e == hipSuccess) {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, stamp_dev, 64, hipMemcpyDeviceToHost);
+        const double n = h[5] ? (double)h[5] : 1.0;
+        fprintf(stderr, "STAMPS front %dx%d | per wave-tile cycles: barrier+raw %.0f  convert %.0f  stem %.0f  conv+tail %.0f  fetch_issue %.0f  (wave-tiles %.0f)\n", L.Hin, L.Win,
+                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n);
+    }
+#endif
+    return e;
 }
 
 }  // namespace obb

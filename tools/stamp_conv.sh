@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 D=oriented-object-detection_amd; B=gpurun_out/stamps_build; mkdir -p $B
 for f in $D/csrc/*.hip; do
-  X=""; [ "$(basename $f)" = conv.hip ] && X="-DOBB_STAMPS"
+  X=""; case "$(basename $f)" in conv.hip|front.hip) X="-DOBB_STAMPS";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno $X -c $f -o $B/$(basename $f).o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libobbhip_stamps.so $B/*.o

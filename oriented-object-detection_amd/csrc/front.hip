@@ -108,6 +108,22 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
         q = q < 6 ? q : 5;
         scvt[ks] = (q >> 1) * kCvtPitch + (q & 1) * 16;
     }
+    constexpr int kStemSlots = 12;
+    int sa_off[kStemSlots], sw_off[kStemSlots];  // per stem slot: byte offset of the pixel's window in the converted image / of its 8 output bytes in the tile
+    unsigned zrow = 0, zcol = 0;                 // bit k: slot k lies in stem row / column -1 of a top / left tile
+#pragma unroll
+    for (int k = 0; k < kStemSlots; ++k) {
+        const int p = min((wave + 4 * k) * 16 + pl, kSP - 1);
+        const int sy = p / kSW, sx = p - sy * kSW;
+        sa_off[k] = (2 * sy) * kCvtPitch + (2 * sx) * 8;
+        sw_off[k] = p * kPST + g * 8;
+        zrow |= (sy == 0 ? 1u : 0u) << k; zcol |= (sx == 0 ? 1u : 0u) << k;
+    }
+    const f32x4 bias0 = f32x4{b0[0], b0[1], b0[2], b0[3]};  // accumulators start at the bias
+    int64_t lane_out[3];  // per pixel fragment: element offset of the lane's 16 output bytes relative to the tile's first pixel
+#pragma unroll
+    for (int mf = 0; mf < 3; ++mf)
+        lane_out[mf] = ((int64_t)(ptyx[mf] >> 16) * P.Wo + (ptyx[mf] & 0xffff)) * P.out_cs + (int64_t)(g >> P.out_bsh) * P.out_ps + ((g & P.out_bmask) << 3);
     auto tile_origin = [&](int t, int &b, int &oy0, int &ox0) {
         const int tx_i = t % P.tiles_x, r = t / P.tiles_x;
         b = r / P.tiles_y;
@@ -197,29 +213,25 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
         STAMP(1)
         fetch(min(t + 1, t1 - 1));  // next tile's bytes, under this tile's arithmetic (unconditional: the last tile re-reads its own; keeps the count exact)
         STAMP(4)
-        // ---- stem: 46 fragments of 16 stem pixels, dealt round-robin to the waves (pixel p = j*16 + pl advances by 64 = 2 rows + 10)
-        {
-            int p = wave * 16 + pl, sy = p / kSW, sx = p - sy * kSW;
-            for (int j = wave; j * 16 < kSP; j += 4) {
-                const bool real = p < kSP;
-                const int syc = real ? sy : kSW - 1, sxc = real ? sx : kSW - 1;
-                const char *ap = cvt + (2 * syc) * kCvtPitch + (2 * sxc) * 8;
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- stem: 46 fragments of 16 stem pixels, dealt round-robin to the waves (12 slots per wave, addresses precomputed; the two spare
+        //      slots of waves 2 and 3 repeat pixel 728: same value to the same address, so nothing in the loop is conditional)
+        const unsigned zmask = border ? ((oy0 == 0 ? zrow : 0u) | (ox0 == 0 ? zcol : 0u)) : 0u;  // bit k: slot k is model.1's zero padding
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) acc = HX<F16>::mfma(w0[ks], *reinterpret_cast<const hx8 *>(ap + scvt[ks]), acc);
-                float v[4];
+        for (int k = 0; k < kStemSlots; ++k) {
+            const char *ap = cvt + sa_off[k];
+            f32x4 acc = bias0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = silu_f(acc[i] + b0[i]);
-                uint2 o;
-                o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]);
-                if (border) {  // stem row / column -1 = model.1's zero padding (top / left tiles only)
-                    const unsigned m = (unsigned)-(int)(2 * oy0 - 1 + syc >= 0 && 2 * ox0 - 1 + sxc >= 0);
-                    o.x &= m; o.y &= m;
-                }
-                if (real) *reinterpret_cast<uint2 *>(act + p * kPST + g * 8) = o;
-                p += 64; sy += 2; sx += 10;
-                if (sx >= kSW) { sx -= kSW; ++sy; }
+            for (int ks = 0; ks < 2; ++ks) acc = HX<F16>::mfma(w0[ks], *reinterpret_cast<const hx8 *>(ap + scvt[ks]), acc);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = silu_f(acc[i]);
+            uint2 o;
+            o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]);
+            if (border) {  // (tile-uniform)
+                const unsigned m = ((zmask >> k) & 1u) - 1u;  // 0 where padded
+                o.x &= m; o.y &= m;
             }
+            *reinterpret_cast<uint2 *>(act + sw_off[k]) = o;
         }
         __syncthreads();
         STAMP(2)
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
 #pragma unroll
         for (int mf = 0; mf < 3; ++mf)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < 2; ++f) acc[mf][f] = f32x4{b1[f * 4 + 0], b1[f * 4 + 1], b1[f * 4 + 2], b1[f * 4 + 3]};
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
             hx8 a[3];
@@ -239,32 +251,29 @@ __global__ __launch_bounds__(256, 2) void k_front(const FrontParams P) {
 #pragma unroll
                 for (int f = 0; f < 2; ++f) acc[mf][f] = HX<F16>::mfma(w1[ks][f], a[mf], acc[mf][f]);
         }
-        // ---- + bias, SiLU, 16 bit -> the 1x1 from registers -> + bias, SiLU, 16 bit -> store
+        bf16_t *const otile = P.out + (int64_t)b * P.out_bs + P.out_co + ((int64_t)oy0 * P.Wo + ox0) * P.out_cs;
+        // ---- SiLU, 16 bit -> the 1x1 from registers -> + bias, SiLU, 16 bit -> store
 #pragma unroll
         for (int mf = 0; mf < 3; ++mf) {
             float v[8];
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[f * 4 + i] = silu_f(acc[mf][f][i] + b1[f * 4 + i]);
+                for (int i = 0; i < 4; ++i) v[f * 4 + i] = silu_f(acc[mf][f][i]);
             uint4 y;
             y.x = HX<F16>::pack2(v[0], v[1]); y.y = HX<F16>::pack2(v[2], v[3]); y.z = HX<F16>::pack2(v[4], v[5]); y.w = HX<F16>::pack2(v[6], v[7]);
             hx8 a2;
             __builtin_memcpy(&a2, &y, 16);
             f32x4 acc2[2];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) acc2[f] = HX<F16>::mfma(w2[f], a2, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int f = 0; f < 2; ++f) acc2[f] = HX<F16>::mfma(w2[f], a2, f32x4{b2[f * 4 + 0], b2[f * 4 + 1], b2[f * 4 + 2], b2[f * 4 + 3]});
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[f * 4 + i] = silu_f(acc2[f][i] + b2[f * 4 + i]);
+                for (int i = 0; i < 4; ++i) v[f * 4 + i] = silu_f(acc2[f][i]);
             uint4 o;
             o.x = HX<F16>::pack2(v[0], v[1]); o.y = HX<F16>::pack2(v[2], v[3]); o.z = HX<F16>::pack2(v[4], v[5]); o.w = HX<F16>::pack2(v[6], v[7]);
-            {
-                const int64_t opix = (int64_t)(oy0 + (ptyx[mf] >> 16)) * P.Wo + ox0 + (ptyx[mf] & 0xffff);
-                bf16_t *op = P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs + (int64_t)(g >> P.out_bsh) * P.out_ps + ((g & P.out_bmask) << 3);
-                *reinterpret_cast<uint4 *>(op) = o;
-            }
+            *reinterpret_cast<uint4 *>(otile + lane_out[mf]) = o;
         }
         STAMP(3)
         STAMP_TILE

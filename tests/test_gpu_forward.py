@@ -96,8 +96,9 @@ def test_upsample_concat_read_in_place(ops, net_n, h, w, B):
 @pytest.mark.parametrize("h,w,B,ch", [(416, 416, 3, 3), (832, 416, 1, 3), (416, 416, 2, 4)])
 def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
     """model.0 + model.1 + model.2.cv1 in one launch (front.hip, tiles whose sides are multiples of 52) against the stem kernel + the fused
-    conv pair: the same k order everywhere; the only difference is the final rounding of x * sigmoid(x) (one step instead of two), so the
-    16-bit activations may differ by one ulp in a small fraction of the elements and the head stays within the fused-form tolerance."""
+    conv pair: the same k order everywhere; the differences are the accumulators starting at the bias (instead of adding it last) and the
+    final rounding of x * sigmoid(x) (one step instead of two), so 16-bit activations flip by an ulp here and there, a flipped stem value
+    moves the values behind it by a few ulps, and the head stays within the fused-form tolerance."""
     import make_weights
     blob = open(make_weights.ensure("n", 12, ch, 0), "rb").read()
     x = torch.as_tensor(np.random.default_rng(7 + h + w).integers(0, 256, (B, h, w, ch), dtype=np.uint8)).cuda()
@@ -111,9 +112,11 @@ def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
     got = ops.debug_activation("model.2.cv1", B, h, w).float()
     torch.cuda.synchronize()
     d = (got - ref).abs()
-    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device="cuda")) * 2.0 ** -10  # one 16-bit ulp at the value's binade (upper bound)
-    assert bool((d <= ulp).all()), float((d / ulp).max())
-    assert float((d > 0).float().mean()) < 0.01
+    # 16-bit ulps at the value's binade, with a floor of 2^-2: an output near zero is the 1x1 sum of O(1) inputs that may each have flipped
+    ulp = torch.maximum(ref.abs(), torch.tensor(0.25, device="cuda")) * 2.0 ** -10
+    print("front vs separate: max ulps", float((d / ulp).max()), "fraction differing", float((d > 0).float().mean()))
+    assert float((d / ulp).max()) <= 8.0, float((d / ulp).max())
+    assert float((d > 0).float().mean()) < 0.05
     dh = (got_head[..., :65 + 12] - ref_head[..., :65 + 12]).abs()
     assert float(dh.max()) < 0.5 and float(dh.mean()) < 1e-2, (float(dh.max()), float(dh.mean()))
 
@@ -159,7 +162,7 @@ def test_cv1_behind_stride2_conv(ops, net_n, h, w, B):
     assert not any("+model.2.cv1" in l for l in ops.debug_plan(h, w))
     ref_head = ops.forward(x).clone()
     ref = {n: ops.debug_activation(n, B, h, w).clone() for n in ("model.2.cv1", "model.4.cv1")}
-    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, front=False)  # (the one-launch front has its own test: different rounding points)
     plan = ops.debug_plan(h, w)
     fused = [l for l in plan if "model.1+model.2.cv1" in l or "model.3+model.4.cv1" in l]
     assert len(fused) == (2 if (h, w) == (416, 416) else 0), plan   # 13x13 output tiles only (every level of a full 416-px tile)
@@ -223,7 +226,8 @@ def test_fused_bottleneck_stripes(ops, net_n):
     head_ref = ops.forward(x).clone()
     for name in ("model.2.m.0.cv2", "model.4.m.0.cv2", "model.16.m.0.cv2"):
         ref[name] = ops.debug_activation(name, B, h, w).clone()
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, bneck_cv2=False)  # keep y2 observable: the closing 1x1 as its own launch (fused form: next test)
+    # keep y2 observable: the closing 1x1 as its own launch (fused form: next test); front off: the reference side (tail=False) has no one-launch front
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, bneck_cv2=False, front=False)
     plan = ops.debug_plan(h, w)
     assert sum(l.startswith("bneck ") for l in plan) == 3, plan
     head = ops.forward(x)

@@ -226,13 +226,25 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const double *__restrict__
     members[atomicAdd(&cursor[sort_bucket(sort_image(key[i]), *info)], 1)] = (int32_t)i;
 }
 
+// rank inside the bucket: a thread per row walks its bucket's members.  Buckets above kSortHot members (many EQUAL keys: confidences that
+// went through 16-bit arithmetic take a few thousand distinct values) would cost members^2 thread-serial steps: those are listed instead
+// (by the row that is the bucket's first member) and ranked by k_sort_hot, a whole workgroup per bucket.
+static constexpr int kSortHot = 192, kSortHotMax = 4096, kSortHotTile = 4096;
 __global__ __launch_bounds__(256) void k_sort_rank(const double *__restrict__ key, int64_t n, const SortInfo *__restrict__ info, const int32_t *__restrict__ start,
-                                                  const int32_t *__restrict__ members, int32_t *__restrict__ order) {
+                                                  const int32_t *__restrict__ members, int32_t *__restrict__ order, int32_t *__restrict__ hot /* [0] = count, then bucket ids */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long ki = sort_image(key[i]);
     const int b = sort_bucket(ki, *info);
     const int lo = start[b], hi = start[b + 1];
+    if (hi - lo > kSortHot) {
+        if (members[lo] == (int32_t)i) {  // one work item per 1024 members of the bucket
+            const int nchunk = (hi - lo + 1023) >> 10;
+            const int slot = atomicAdd(&hot[0], nchunk);
+            for (int c = 0; c < nchunk && slot + c < kSortHotMax; ++c) { hot[1 + 2 * (slot + c)] = b; hot[2 + 2 * (slot + c)] = c; }
+        }
+        return;
+    }
     int r = lo;
     for (int m = lo; m < hi; ++m) {
         const int j = members[m];
@@ -240,6 +252,39 @@ __global__ __launch_bounds__(256) void k_sort_rank(const double *__restrict__ ke
         r += (kj > ki) | ((kj == ki) & (j < (int)i));
     }
     order[r] = (int32_t)i;
+}
+
+// one workgroup per listed work item = 1024 members of a hot bucket (grid-stride over the list): the bucket's (key image, row) pairs go
+// through LDS in tiles and every thread ranks its member against each tile (LDS broadcasts).  The list cannot overflow: an item stands
+// for more than kSortHot rows or a full 1024, and the host takes this path for n <= kSortHot * kSortHotMax only.
+__global__ __launch_bounds__(1024) void k_sort_hot(const double *__restrict__ key, const SortInfo *__restrict__ info, const int32_t *__restrict__ start,
+                                                  const int32_t *__restrict__ members, int32_t *__restrict__ order, const int32_t *__restrict__ hot) {
+    __shared__ unsigned long long tk[kSortHotTile];
+    __shared__ int32_t tj[kSortHotTile];
+    const int nhot = min(hot[0], kSortHotMax);
+    for (int h = blockIdx.x; h < nhot; h += gridDim.x) {
+        const int b = hot[1 + 2 * h], lo = start[b], hi = start[b + 1];
+        const int m = lo + hot[2 + 2 * h] * 1024 + (int)threadIdx.x;
+        const int ii = m < hi ? members[m] : -1;
+        const unsigned long long ki = ii >= 0 ? sort_image(key[ii]) : 0ull;
+        int r = lo;
+        for (int t0 = lo; t0 < hi; t0 += kSortHotTile) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < kSortHotTile && t0 + t < hi; t += 1024) {
+                const int j = members[t0 + t];
+                tj[t] = j; tk[t] = sort_image(key[j]);
+            }
+            __syncthreads();
+            const int cnt = min(kSortHotTile, hi - t0);
+#pragma unroll 4
+            for (int t = 0; t < cnt; ++t) {
+                const unsigned long long kj = tk[t];
+                r += (kj > ki) | ((kj == ki) & (tj[t] < ii));
+            }
+        }
+        if (ii >= 0) order[r] = ii;
+        __syncthreads();
+    }
 }
 
 // ---- suppression pairs of the dense merge through a uniform grid (n >= kGridMin, thr > 0): two envelopes can only overlap if their
@@ -1067,9 +1112,9 @@ int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *or
     OBB_REQUIRE(ctx, ctx && n >= 0 && n < (1ll << 31), "obb_sort_desc_stable: bad n");
     if (n == 0) return OBB_OK;
     OBB_REQUIRE(ctx, key && order, "obb_sort_desc_stable: NULL buffer");
-    if (n >= kBucketSortMin) {  // bucketed O(n) form, same order element for element
+    if (n >= kBucketSortMin && n <= (int64_t)kSortHot * kSortHotMax) {  // bucketed O(n) form, same order element for element (the bound: every hot bucket fits the list)
         hipStream_t st = (hipStream_t)s;
-        int32_t *buf = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)n + 2 * (size_t)kSortBuckets + 64));
+        int32_t *buf = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)n + 2 * (size_t)kSortBuckets + 64 + 2 * kSortHotMax + 8));
         if (!buf) return set_error(ctx, OBB_ERR_HIP, "obb_sort_desc_stable: workspace allocation failed");
         int32_t *hist = buf, *start = buf + kSortBuckets + 8, *members = buf + 2 * kSortBuckets + 32;
         SortInfo *info = (SortInfo *)(buf + 2 * kSortBuckets + 16);
@@ -1079,8 +1124,12 @@ int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *or
         hipLaunchKernelGGL(k_sort_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, hist);
         hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, kSortBuckets, start, cursor);
         hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, cursor, members);
+        int32_t *hot = members + n + 8;  // [0] = number of buckets above kSortHot members, then their ids
+        OBB_HIP(ctx, hipMemsetAsync(hot, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_sort_rank, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, (const int32_t *)start,
-                           (const int32_t *)members, order);
+                           (const int32_t *)members, order, hot);
+        hipLaunchKernelGGL(k_sort_hot, dim3(256), dim3(1024), 0, st, key, (const SortInfo *)info, (const int32_t *)start, (const int32_t *)members, order,
+                           (const int32_t *)hot);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }

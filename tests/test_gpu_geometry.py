@@ -138,6 +138,19 @@ def test_merge_idempotent_at_scale(ops):
         assert torch.equal(k2, keep), huge
 
 
+def test_sort_with_heavy_ties(ops):
+    """confidences that went through 16-bit arithmetic: a few thousand distinct values, so single key buckets hold thousands of equal keys
+    (ranked by a workgroup per bucket); order must still be the stable descending order"""
+    rng = np.random.default_rng(11)
+    for n, kinds in ((20000, 40), (70000, 3), (9000, 1)):
+        s = rng.choice(rng.uniform(0.25, 1.0, kinds).astype(np.float16).astype(np.float64), n)
+        mix = rng.integers(0, n, n // 3)
+        s[mix] = rng.uniform(0.25, 1.0, len(mix)).astype(np.float32)  # a third of the rows with (nearly) unique keys in between
+        order = ops.sort_desc_stable(dev(s, torch.float64)).cpu().numpy()
+        exp = np.argsort(-s, kind="stable")
+        assert np.array_equal(order, exp), (n, kinds)
+
+
 def test_merge_segments_vs_oracle(ops):
     rng = np.random.default_rng(3)
     sizes = [0, 1, 5, 300, 0, 64, 65, 512, 17]

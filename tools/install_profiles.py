@@ -11,9 +11,9 @@ shutil.copy(O + "/layers32.txt", R + "forward_f32_layers_b256.txt")
 shutil.copy(newest(O + "/prof_f32/*/*_kernel_stats.csv"), R + "bench_f32_kernel_stats_sequential.csv")
 shutil.copy(O + "/postproc.txt", R + "postproc.txt")
 shutil.copy(O + "/merge_scaling.txt", R + "merge_scaling.txt")
-open(R + "conv_phase_stamps.txt", "w").write("# tools/stamp_conv.sh: s_memtime stamps inside k_conv_igemm (diagnostic build), one eager forward of 256 tiles, fp16;\n# cycles per wave and tile spent in: waiting at the top-of-stage barrier | LDS staging (incl. the wait for the prefetched global loads) |\n# issuing the next prefetch | the MFMA k loop | the epilogue (bias, SiLU, stores)\n" + "".join(l for l in open(O + "/stamps.txt") if l.startswith("STAMPS")))
+open(R + "conv_phase_stamps.txt", "w").write("# tools/stamp_conv.sh: s_memtime stamps inside k_conv_igemm / k_conv3_pair / k_front (diagnostic build), one eager forward of 256 tiles, fp16;\n# cycles per wave and tile, phases as named on each line (k_conv_igemm: waiting at the top-of-stage barrier | LDS staging incl. the wait for the\n# prefetched global loads | issuing the next prefetch | the MFMA k loop (issue only) | the epilogue (bias, SiLU, stores))\n" + "".join(l for l in open(O + "/stamps.txt") if l.startswith("STAMPS")))
 shutil.copy(newest(O + "/pptrace/*/*_kernel_stats.csv"), R + "decode_nms_kernel_stats.csv")
-KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image", "k_dwpw_stripe", "_f32")
+KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_front", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image", "k_dwpw_stripe", "_f32")
 def load(d):
     plan = [l for l in open(d + "/plan.txt").read().strip().split("\n") if not l.startswith("total")]
     disp = collections.OrderedDict()

@@ -59,7 +59,7 @@ struct ConvLaunch {
 struct ConvTiling { int TH, TW, MF, NF, CK; };
 
 // chooses tile shape / fragment blocking for a layer
-ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout);
+ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout, bool pair = true);  // pair: 64 -> 64-cout 3x3 layers on k_conv3_pair
 
 // Host: repack fp32 OIHW weights into MFMA A-operand fragment order (bf16, RNE):
 //   [cout_block][stage][kstep][nf][lane 0..63][8]

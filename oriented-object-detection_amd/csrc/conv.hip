@@ -811,7 +811,7 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 int conv_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 8) + 3) / 4; }
 
-ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) {
+ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout, bool pair) {
     ConvTiling t;
     t.NF = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4);
     if (ks == 1) {
@@ -837,8 +837,7 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout) 
     //  reads, 7 KiB per 12 MFMAs and wave, not by the per-stage global-memory latency)
     if (stride == 1 && t.MF == 3 && (cin == 32 || cin == 64) && (t.NF == 2 || t.NF == 1)) t.CK = cin;
     // 64 -> 64-cout groups: the same single-stage packing, run by k_conv3_pair (two half-groups per CU sharing the resident weights)
-    static const int pair_on = getenv("OBB_PAIR") ? atoi(getenv("OBB_PAIR")) : 1;
-    if (pair_on && stride == 1 && t.MF == 3 && cin == 64 && t.NF == 4) t.CK = 64;
+    if (pair && stride == 1 && t.MF == 3 && cin == 64 && t.NF == 4) t.CK = 64;
     return t;
 }
 

@@ -18,7 +18,7 @@ struct Model;  // engine.hip
 // tests compare the two on identical inputs.  graph / fwd_split / microbatch steer how a forward is issued (their defaults may be
 // preset from the environment for profiling runs: OBB_GRAPH, OBB_FWD_SPLIT, OBB_MICROBATCH -- read once per context).
 struct EngineOpts {
-    bool tail = true, tail16 = true, bneck = true, bneck_cv2 = true, c3kimg = true, dwpw = true, upfold = true, stem = true, front = true, hmerge = true,
+    bool tail = true, tail16 = true, bneck = true, bneck_cv2 = true, c3kimg = true, dwpw = true, upfold = true, stem = true, front = true, pair = true, hmerge = true,
          sppf_fuse = true, attn_mfma = true, graph = true;
     int fwd_split = 2, microbatch = 1024;
 };

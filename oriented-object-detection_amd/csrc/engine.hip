@@ -236,7 +236,7 @@ struct Builder {
         if (!r || !r2 || err) return false;
         if (r->g != 1 || r2->g != 1 || r2->k != 1 || r2->s != 1 || r2->act || r2->c1 != r->c2 || r->s != 1) return false;
         int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
-        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo);
+        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo, M.o.pair);
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2);
     }
 
@@ -248,7 +248,7 @@ struct Builder {
         if (!r || !r2 || err) return false;
         if (r->g != 1 || r2->g != 1 || r->k != 3 || r2->k != 1 || r2->s != 1 || !r2->act || !r->act || r2->c1 != r->c2) return false;
         int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
-        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo);
+        ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo, M.o.pair);
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true);
     }
 
@@ -345,7 +345,7 @@ struct Builder {
             P.named[name] = out;
             return;
         }
-        ConvTiling t = plan_conv(r->k, r->s, cin, r->c2, op.Ho, op.Wo);
+        ConvTiling t = plan_conv(r->k, r->s, cin, r->c2, op.Ho, op.Wo, M.o.pair);
         if (in_u8) t.CK = 8;
         ConvLaunch &L = op.conv;
         L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act;
@@ -1123,7 +1123,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         // "graph", "fwd_split" and "microbatch", which steer how obb_forward issues its launches from the next call on
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
-            {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front},
+            {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
             {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }

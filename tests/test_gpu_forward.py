@@ -121,6 +121,28 @@ def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
     assert float(dh.max()) < 0.5 and float(dh.mean()) < 1e-2, (float(dh.max()), float(dh.mean()))
 
 
+def test_pair_kernel_matches_staged_kernel(ops, net_n):
+    """k_conv3_pair (64 -> 64-cout 3x3 convs of the head's box branch: weights resident in LDS, two half-groups per workgroup, all 64 input
+    channels in one k loop, the fp32 tail straight from registers) against k_conv_igemm on the same layers (four 16-channel stages): the k
+    sums are split differently, so 16-bit values flip by an ulp here and there; the fp32 box logits stay within the fused-form tolerance."""
+    B, h, w = 3, 416, 416
+    x = torch.as_tensor(_tiles(77, B, h, w)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, pair=False)
+    assert not any("CK64" in l and "cv2.0.0" in l for l in ops.debug_plan(h, w))
+    ref_head = ops.forward(x).clone()
+    ref = ops.debug_activation("model.23.cv2.0.0", B, h, w).clone().float()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    assert any("CK64" in l and "cv2.0.0" in l for l in ops.debug_plan(h, w))
+    head = ops.forward(x)
+    got = ops.debug_activation("model.23.cv2.0.0", B, h, w).float()
+    torch.cuda.synchronize()
+    ulp = (2.0 ** -10 if net_n.prec == "f16" else 2.0 ** -7) * torch.maximum(ref.abs(), torch.tensor(0.25, device="cuda"))
+    d = (got - ref).abs()
+    assert float((d / ulp).max()) <= 2.0 and float((d > 0).float().mean()) < 0.05, (float((d / ulp).max()), float((d > 0).float().mean()))
+    dh = (head[..., :77] - ref_head[..., :77]).abs()
+    assert float(dh.max()) < (0.25 if net_n.prec == "f16" else 2.0) and float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), (float(dh.max()), float(dh.mean()))
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
 def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
     """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""

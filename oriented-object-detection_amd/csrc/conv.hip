@@ -290,6 +290,15 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
     if constexpr (!IN_U8) { plan_tile(t0); load_stage(0); }
     else load_u8(t0);
     bool w_resident = WRES;
+    // EXACT: register-direct 16-bit stores with a compile-time count per tile.  Loads and stores retire through ONE in-order counter
+    // (vmcnt): the wait for the next tile's prefetched operands at the top of stage 0 must leave this tile's stores (issued after them) in
+    // flight, which the compiler can only do if their number is the same on every path into that wait.  Hence: stage 0 is a separate copy
+    // of the stage body (inside the stage loop the prefetch is the youngest operation, at the top of a tile 2*MF stores are younger), the
+    // prefetch and the stores are unconditional (the last tile re-reads itself; lanes without an output pixel store into a sink), and the
+    // prologue's loads are settled before the loop so that the loop-entry state is "nothing outstanding".  Without this every tile
+    // drained its predecessor's stores before touching LDS (ISA: s_waitcnt vmcnt(0) at the top of every stage).
+    constexpr bool EXACT = DIRECT && !VCAT && !WRES;
+    if constexpr (EXACT) __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));  // vmcnt(0)
     STAMP_INIT
 
     for (int t = t0; t < t1; ++t) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int stage = 0; stage < P.nstage; ++stage) {
+        auto stage_body = [&](int stage) {
             __syncthreads();
             STAMP(0)
             // ---- stage this channel chunk of the input tile (and, unless resident, the stage's weights) into LDS
@@ -317,6 +326,10 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                 // prefetch into registers: the next channel stage of this tile, or stage 0 of the next tile; the HBM/L2 latency
                 // hides under this stage's MFMAs (and under the epilogue)
                 if constexpr (WRES) { if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); } }
+                else if constexpr (EXACT) {
+                    if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
+                    else { if (P.nstage > 1) load_w(0); plan_tile(min(t + 1, t1 - 1)); load_stage(0); }
+                }
                 else if (stage + 1 < P.nstage) { load_w(stage + 1); load_stage(stage + 1); }
                 else if (t + 1 < t1) { plan_tile(t + 1); load_stage(0); if (P.nstage > 1) load_w(0); }
                 STAMP(2)
@@ -373,6 +386,12 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                     mfma_step(wcur, a);
                 }
             }
+        };
+        if constexpr (EXACT) {
+            stage_body(0);
+            for (int stage = 1; stage < P.nstage; ++stage) stage_body(stage);
+        } else {
+            for (int stage = 0; stage < P.nstage; ++stage) stage_body(stage);
         }
         STAMP(3)
         w_resident = (P.nstage == 1);  // single-stage layers keep their weights in LDS for every following tile
@@ -409,7 +428,8 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
         for (int mf = 0; mf < MF; ++mf) {
             int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
             bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout) && !(P.dbg & 8);
-            if (!ok) continue;
+            if constexpr (!EXACT) { if (!ok) continue; }
+            else if (!ok) { ty = 0; tx = 0; }  // (addresses stay in range; the stores below go to the sink)
             const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
             float v[NF * 4];
 #pragma unroll
@@ -464,7 +484,11 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                     o.x = HX<F16>::pack2(v[h * 8 + 0], v[h * 8 + 1]); o.y = HX<F16>::pack2(v[h * 8 + 2], v[h * 8 + 3]);
                     o.z = HX<F16>::pack2(v[h * 8 + 4], v[h * 8 + 5]); o.w = HX<F16>::pack2(v[h * 8 + 6], v[h * 8 + 7]);
                     const int occ = cb * 2 * NF + g * (NF / 2) + h;  // 8-channel chunk index inside the output slice
-                    if (occ * 8 + 8 <= P.cout)
+                    if constexpr (EXACT) {  // one store per piece on every path: lanes without a pixel / beyond the last cout write the sink
+                        bf16_t *dst = obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3);
+                        if (!ok || occ * 8 + 8 > P.cout) dst = const_cast<bf16_t *>(P.lut) + 256 + lane * 8;
+                        *reinterpret_cast<uint4 *>(dst) = o;
+                    } else if (occ * 8 + 8 <= P.cout)
                         *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = o;
                 }
             } else {  // 16-bit outputs are staged through LDS so that the global stores below are whole 16-B-per-lane row pieces

@@ -1095,7 +1095,7 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     // u8 -> half(v / 255): the predictor's `im.float() / 255` followed by the 16-bit storage rounding, exactly
     std::vector<bf16_t> lut(256);
     for (int v = 0; v < 256; ++v) lut[v] = host_to_half((float)v / 255.0f, M->f16);
-    OBB_HIP(ctx, hipMalloc((void **)&M->lut_dev, 512));
+    OBB_HIP(ctx, hipMalloc((void **)&M->lut_dev, 512 + 1024));  // + a 1-KiB sink for the stores of lanes without an output pixel (conv.hip EXACT)
     OBB_HIP(ctx, hipMemcpy(M->lut_dev, lut.data(), 512, hipMemcpyHostToDevice));
     ctx->model = M;
     return OBB_OK;

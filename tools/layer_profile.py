@@ -31,10 +31,11 @@ else:
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/layers"
     os.makedirs(out, exist_ok=True)
-    m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416, precision=os.environ.get("OBB_PREC", "f16"))
-    open(out + "/plan.txt", "w").write("\n".join(ops.debug_plan(416, 416)))
+    S = int(os.environ.get("OBB_SIZE", "416"))  # tile side (the 128-px scale of the dual-scale config: OBB_SIZE=128, weights of seed 1)
+    m = YOLO(make_weights.ensure("n", 12, 3, 0 if S == 416 else 1), imgsz=S, precision=os.environ.get("OBB_PREC", "f16"))
+    open(out + "/plan.txt", "w").write("\n".join(ops.debug_plan(S, S)))
     open(out + "/B.txt", "w").write(str(B))
-    tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()
+    tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, S, S, 3), dtype=np.uint8)).cuda()
     for _ in range(3):
         ops.forward(tiles)
     torch.cuda.synchronize()

@@ -178,6 +178,17 @@ int obb_results(obb_ctx *ctx, const float *det, const float *lb, int64_t n, floa
 int obb_probiou_loss(obb_ctx *ctx, const float *pred, const float *target, const float *weight, int64_t n, float target_scores_sum,
                      float *loss, float *grad_pred, obb_stream_t s);
 
+/* f1 (second slice): the other two terms of v8OBBLoss, forward and backward in one pass each.
+ * DFL (ultralytics DFLoss inside RotatedBboxLoss): pred_dist float[n*4*reg_max] logits of the n matched anchors' four sides, target_ltrb
+ * float[n*4] = bbox2dist(anchor, xyxy(target), reg_max - 1) (clamped to [0, reg_max - 1.01] here as the reference does), weight float[n]
+ * (NULL = 1); *loss = sum_i mean_side(CE(l) wl + CE(r) wr) weight_i / target_scores_sum; grad_pred float[n*4*reg_max].  reg_max must be 16. */
+int obb_dfl_loss(obb_ctx *ctx, const float *pred_dist, const float *target_ltrb, const float *weight, int64_t n, int32_t reg_max,
+                 float target_scores_sum, float *loss, float *grad_pred, obb_stream_t s);
+/* classification term: BCEWithLogitsLoss(reduction="none")(logits, targets).sum() / target_scores_sum over n = batch * anchors * classes
+ * elements; grad_logits float[n] = (sigmoid(logit) - target) / target_scores_sum. */
+int obb_bce_loss(obb_ctx *ctx, const float *logits, const float *targets, int64_t n, float target_scores_sum, float *loss, float *grad_logits,
+                 obb_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,3 +30,23 @@ def probiou_loss(pred, target, weight, target_scores_sum):
     iou = probiou(pred, target)
     w = weight if weight is not None else torch.ones(pred.shape[0], dtype=pred.dtype)
     return ((1.0 - iou) * w[:, None]).sum() / target_scores_sum
+
+
+def dfl_loss(pred_dist, target_ltrb, weight, target_scores_sum, reg_max=16):
+    """ultralytics DFLoss as used by RotatedBboxLoss: target clamped to [0, reg_max - 1 - 0.01], cross entropy against the two neighbouring
+    bins weighted by the distances to them, mean over the 4 sides, times weight, over target_scores_sum.  pred_dist [n, 4*reg_max]."""
+    import torch.nn.functional as F
+    t = target_ltrb.clamp(0, reg_max - 1 - 0.01)
+    tl = t.long()
+    tr = tl + 1
+    wl = tr - t
+    wr = 1 - wl
+    pd = pred_dist.reshape(-1, reg_max)
+    l = (F.cross_entropy(pd, tl.reshape(-1), reduction="none").reshape(tl.shape) * wl + F.cross_entropy(pd, tr.reshape(-1), reduction="none").reshape(tl.shape) * wr).mean(-1, keepdim=True)
+    w = weight if weight is not None else torch.ones(t.shape[0], dtype=pred_dist.dtype)
+    return (l * w[:, None]).sum() / target_scores_sum
+
+
+def bce_loss(logits, targets, target_scores_sum):
+    import torch.nn.functional as F
+    return F.binary_cross_entropy_with_logits(logits, targets, reduction="none").sum() / target_scores_sum

@@ -80,9 +80,114 @@ __global__ __launch_bounds__(256) void k_sum_f32(const float *__restrict__ v, in
     if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] * (double)scale);
 }
 
+
+// ---- DFL (distribution focal loss) of the box branch: per (box, side) a 16-way distribution over integer distances; the target distance
+// t in [0, reg_max - 1) is shared out between its two neighbouring bins:  l = CE(logits, floor t) * (ceil' - t) + CE(logits, floor t + 1) *
+// (t - floor t); per box the mean over the 4 sides, times the box weight, over target_scores_sum (ultralytics DFLoss + RotatedBboxLoss).
+// One thread per (box, side): 16 logits in, 16 gradients out: d l / d logit_k = softmax_k - (wl [k = tl] + wr [k = tr]).
+template <int R>
+__global__ __launch_bounds__(256) void k_dfl_loss(const float *__restrict__ logits, const float *__restrict__ target, const float *__restrict__ weight,
+                                                 int64_t n4, float inv_tss, float *__restrict__ loss_elem, float *__restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (box, side)
+    if (i >= n4) return;
+    float x[R];
+#pragma unroll
+    for (int k = 0; k < R; k += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(logits + i * R + k);
+        x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+    }
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) m = fmaxf(m, x[k]);
+    float e[R], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { e[k] = expf(x[k] - m); se += e[k]; }
+    const float lse = m + logf(se);
+    const float t = fminf(fmaxf(target[i], 0.0f), (float)(R - 1) - 0.01f);
+    const int tl = (int)t, tr = tl + 1;
+    const float wl = (float)tr - t, wr = 1.0f - wl;
+    float xl = 0.f, xr = 0.f;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { xl = k == tl ? x[k] : xl; xr = k == tr ? x[k] : xr; }
+    const float wt = (weight ? weight[i >> 2] : 1.0f) * 0.25f;
+    loss_elem[i] = ((lse - xl) * wl + (lse - xr) * wr) * wt;
+    const float gs = wt * inv_tss, inv_se = 1.0f / se;
+#pragma unroll
+    for (int k = 0; k < R; k += 4) {
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (e[k + j] * inv_se - (k + j == tl ? wl : 0.f) - (k + j == tr ? wr : 0.f)) * gs;
+        *reinterpret_cast<float4 *>(grad + i * R + k) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+// ---- classification term: BCEWithLogitsLoss(reduction="none")(logits, targets).sum() / target_scores_sum (v8OBBLoss), element-wise:
+// l = max(x, 0) - x t + log(1 + exp(-|x|)),  d l / d x = sigmoid(x) - t
+__global__ __launch_bounds__(256) void k_bce_loss(const float *__restrict__ logits, const float *__restrict__ target, int64_t n, float inv_tss,
+                                                 float *__restrict__ loss_elem, float *__restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = logits[i], t = target[i];
+    const float ea = expf(-fabsf(x));
+    loss_elem[i] = fmaxf(x, 0.0f) - x * t + log1pf(ea);
+    const float sig = x >= 0.0f ? 1.0f / (1.0f + ea) : ea / (1.0f + ea);
+    grad[i] = (sig - t) * inv_tss;
+}
+
 }  // namespace obb
 
 using namespace obb;
+
+// deterministic sum of elem[0..n) * scale -> *loss (tree of k_sum_f32 launches)
+static int sum_to_scalar(obb_ctx *ctx, const float *elem, int64_t n, float scale, float *loss, hipStream_t st, const char *who) {
+    const int64_t nb1 = cdiv(n, 4096), nb2 = cdiv(nb1, 4096);
+    OBB_REQUIRE(ctx, nb2 <= 4096, "%s: n too large", who);
+    float *part = (float *)ctx->workspace(WS_GEOM_B, sizeof(float) * (size_t)(nb1 + nb2 + 8));
+    if (!part) return set_error(ctx, OBB_ERR_HIP, "%s: workspace allocation failed", who);
+    if (nb1 == 1) {
+        hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(256), 0, st, elem, n, scale, loss);
+    } else {
+        hipLaunchKernelGGL(k_sum_f32, dim3((unsigned)nb1), dim3(256), 0, st, elem, n, 1.0f, part);
+        if (nb2 == 1) hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(256), 0, st, (const float *)part, nb1, scale, loss);
+        else {
+            hipLaunchKernelGGL(k_sum_f32, dim3((unsigned)nb2), dim3(256), 0, st, (const float *)part, nb1, 1.0f, part + nb1);
+            hipLaunchKernelGGL(k_sum_f32, dim3(1), dim3(256), 0, st, (const float *)(part + nb1), nb2, scale, loss);
+        }
+    }
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+extern "C" int obb_dfl_loss(obb_ctx *ctx, const float *pred_dist, const float *target_ltrb, const float *weight, int64_t n, int32_t reg_max,
+                            float target_scores_sum, float *loss, float *grad_pred, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && loss, "obb_dfl_loss: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    if (n == 0) { OBB_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), st)); return OBB_OK; }
+    OBB_REQUIRE(ctx, pred_dist && target_ltrb && grad_pred, "obb_dfl_loss: NULL buffer");
+    OBB_REQUIRE(ctx, reg_max == 16, "obb_dfl_loss: reg_max %d unsupported (the OBB head uses 16 bins)", reg_max);
+    OBB_REQUIRE(ctx, target_scores_sum > 0.0f, "obb_dfl_loss: target_scores_sum must be positive");
+    OBB_REQUIRE(ctx, (((uintptr_t)pred_dist | (uintptr_t)grad_pred) & 15) == 0, "obb_dfl_loss: logits and gradient rows must be 16-byte aligned");
+    const int64_t n4 = n * 4;
+    float *elem = (float *)ctx->workspace(WS_GEOM_A, sizeof(float) * (size_t)n4);
+    if (!elem) return set_error(ctx, OBB_ERR_HIP, "obb_dfl_loss: workspace allocation failed");
+    hipLaunchKernelGGL(k_dfl_loss<16>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, pred_dist, target_ltrb, weight, n4, 1.0f / target_scores_sum, elem, grad_pred);
+    OBB_LAUNCH_CHECK(ctx);
+    return sum_to_scalar(ctx, elem, n4, 1.0f / target_scores_sum, loss, st, "obb_dfl_loss");
+}
+
+extern "C" int obb_bce_loss(obb_ctx *ctx, const float *logits, const float *targets, int64_t n, float target_scores_sum, float *loss, float *grad_logits,
+                            obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && loss, "obb_bce_loss: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    if (n == 0) { OBB_HIP(ctx, hipMemsetAsync(loss, 0, sizeof(float), st)); return OBB_OK; }
+    OBB_REQUIRE(ctx, logits && targets && grad_logits, "obb_bce_loss: NULL buffer");
+    OBB_REQUIRE(ctx, target_scores_sum > 0.0f, "obb_bce_loss: target_scores_sum must be positive");
+    float *elem = (float *)ctx->workspace(WS_GEOM_A, sizeof(float) * (size_t)n);
+    if (!elem) return set_error(ctx, OBB_ERR_HIP, "obb_bce_loss: workspace allocation failed");
+    hipLaunchKernelGGL(k_bce_loss, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, logits, targets, n, 1.0f / target_scores_sum, elem, grad_logits);
+    OBB_LAUNCH_CHECK(ctx);
+    return sum_to_scalar(ctx, elem, n, 1.0f / target_scores_sum, loss, st, "obb_bce_loss");
+}
 
 extern "C" int obb_probiou_loss(obb_ctx *ctx, const float *pred, const float *target, const float *weight, int64_t n, float target_scores_sum,
                                 float *loss, float *grad_pred, obb_stream_t s) {

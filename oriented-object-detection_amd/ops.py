@@ -173,6 +173,17 @@ def _probiou_loss(pred: T, target: T, weight: Optional[T], target_scores_sum: fl
     _call("obb_probiou_loss", ctx(pred.device), _p(pred), _p(target), _p(weight), pred.shape[0], float(target_scores_sum), _p(loss), _p(grad_pred), _stream())
 
 
+@_op("dfl_loss", ("loss", "grad_pred"))
+def _dfl_loss(pred_dist: T, target_ltrb: T, weight: Optional[T], reg_max: int, target_scores_sum: float, loss: T, grad_pred: T) -> None:
+    _call("obb_dfl_loss", ctx(pred_dist.device), _p(pred_dist), _p(target_ltrb), _p(weight), target_ltrb.shape[0], int(reg_max), float(target_scores_sum),
+          _p(loss), _p(grad_pred), _stream())
+
+
+@_op("bce_loss", ("loss", "grad_logits"))
+def _bce_loss(logits: T, targets: T, target_scores_sum: float, loss: T, grad_logits: T) -> None:
+    _call("obb_bce_loss", ctx(logits.device), _p(logits), _p(targets), logits.numel(), float(target_scores_sum), _p(loss), _p(grad_logits), _stream())
+
+
 @_op("debug_activation", ("out",))
 def _debug_activation(name: str, B: int, h: int, w: int, out: T) -> None:
     n = C.c_int64(0)
@@ -481,6 +492,34 @@ def letterbox(image, x, y, x2, y2, imgsz):
     out = torch.empty((p["out_h"], p["out_w"], Cc), dtype=torch.uint8, device=img.device)
     _O.letterbox(img, int(x), int(y), int(x2), int(y2), int(imgsz), out)
     return out, p
+
+
+def dfl_loss(pred_dist, target_ltrb, weight=None, target_scores_sum=1.0, reg_max=16):
+    """DFL term of the OBB loss for n matched anchors, forward + backward in one launch: pred_dist [n, 4*reg_max] (or [n*4, reg_max]) logits,
+    target_ltrb [n,4] distances in bins, weight [n] or None -> (loss float32[1], grad [n, 4*reg_max]).  ultralytics DFLoss / RotatedBboxLoss."""
+    t = _chk(target_ltrb, torch.float32, "target_ltrb").reshape(-1, 4)
+    p = _chk(pred_dist, torch.float32, "pred_dist").reshape(t.shape[0], 4 * reg_max)
+    if weight is not None:
+        weight = _chk(weight, torch.float32, "weight").reshape(-1)
+        if weight.shape[0] != t.shape[0]:
+            raise ValueError("dfl_loss: weight length mismatch")
+    loss = torch.zeros(1, dtype=torch.float32, device=p.device)
+    grad = torch.empty_like(p)
+    _O.dfl_loss(p, t, weight, int(reg_max), float(target_scores_sum), loss, grad)
+    return loss, grad
+
+
+def bce_loss(logits, targets, target_scores_sum=1.0):
+    """Classification term of the OBB loss: BCEWithLogits(reduction none)(logits, targets).sum() / target_scores_sum, forward + backward in
+    one launch: logits, targets float32 of equal shape -> (loss float32[1], grad like logits)."""
+    x = _chk(logits, torch.float32, "logits")
+    t = _chk(targets, torch.float32, "targets")
+    if x.shape != t.shape:
+        raise ValueError("bce_loss: shape mismatch")
+    loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x)
+    _O.bce_loss(x, t, float(target_scores_sum), loss, grad)
+    return loss, grad
 
 
 def probiou_loss(pred, target, weight=None, target_scores_sum=1.0):

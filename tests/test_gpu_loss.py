@@ -48,3 +48,51 @@ def test_probiou_loss_forward_and_backward(n):
     p64b = torch.tensor(p, dtype=torch.float64, requires_grad=True)
     (3.0 * ol.probiou_loss(p64b, torch.tensor(t, dtype=torch.float64), None, float(n))).backward()
     assert float((pd2.grad.cpu().double() - p64b.grad).abs().max() / p64b.grad.abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("n", [1, 300, 70000])
+def test_dfl_loss_forward_and_backward(n):
+    """f1, second slice: the DFL term (box-side distributions, 16 bins) against torch's cross_entropy in fp64 (oracle/loss.py)."""
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import loss as L
+    rng = np.random.default_rng(n)
+    logits = rng.normal(0, 2.5, (n, 64)).astype(np.float32)
+    t = rng.uniform(-0.5, 16.5, (n, 4)).astype(np.float32)   # beyond both ends: the clamp of the reference
+    t[rng.uniform(size=(n, 4)) < 0.05] = 7.0                  # exact bin centres
+    w = rng.uniform(0.05, 1.0, n).astype(np.float32)
+    tss = float(w.sum())
+    x = torch.tensor(logits, device="cuda", requires_grad=True)
+    out = L.dfl_loss(x, torch.tensor(t).cuda(), torch.tensor(w).cuda(), tss)
+    (2.0 * out).backward()
+    x64 = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    ref = ol.dfl_loss(x64, torch.tensor(t, dtype=torch.float64), torch.tensor(w, dtype=torch.float64), tss)
+    (2.0 * ref).backward()
+    assert abs(float(out) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(out), float(ref))
+    g, gr = x.grad.cpu().double(), x64.grad
+    assert float((g - gr).abs().max()) <= 2e-5 * float(gr.abs().max()) + 1e-9
+    # weightless form
+    x2 = torch.tensor(logits, device="cuda", requires_grad=True)
+    L.dfl_loss(x2, torch.tensor(t).cuda(), None, float(n)).backward()
+    x64b = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    ol.dfl_loss(x64b, torch.tensor(t, dtype=torch.float64), None, float(n)).backward()
+    assert float((x2.grad.cpu().double() - x64b.grad).abs().max()) <= 2e-5 * float(x64b.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 3549, 12), (64, 3549, 12)])
+def test_bce_loss_forward_and_backward(shape):
+    """f1, second slice: the classification term (BCE with logits, summed, over target_scores_sum) against torch in fp64."""
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import loss as L
+    rng = np.random.default_rng(sum(shape))
+    logits = rng.normal(-4, 4, shape).astype(np.float32)
+    logits.flat[:: max(1, logits.size // 50)] = rng.choice([-90.0, 90.0, 0.0], size=len(logits.flat[:: max(1, logits.size // 50)]))  # saturated logits
+    tgt = np.where(rng.uniform(size=shape) < 0.02, rng.uniform(0.1, 1.0, shape), 0.0).astype(np.float32)
+    tss = max(float(tgt.sum()), 1.0)
+    x = torch.tensor(logits, device="cuda", requires_grad=True)
+    out = L.bce_loss(x, torch.tensor(tgt).cuda(), tss)
+    out.backward()
+    x64 = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    ref = ol.bce_loss(x64, torch.tensor(tgt, dtype=torch.float64), tss)
+    ref.backward()
+    assert abs(float(out) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(out), float(ref))
+    assert float((x.grad.cpu().double() - x64.grad).abs().max()) <= 2e-6 * float(x64.grad.abs().max()) + 1e-12

@@ -62,6 +62,9 @@ def lib():
             raise ImportError(
                 f"{SO_PATH} is missing: the HIP extension has not been built. Run `python -c \"import __graft_entry__ as g; "
                 "g.build()\"` (needs hipcc). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime; it must be the one in the process (tensors, streams and this library share it).  Loading
+        # libobbhip.so first would pull in the system's libamdhip64 instead, and a process with both sees no device through the second.
+        import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         for name, argt in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -1,6 +1,8 @@
 // Context lifetime + error plumbing of libobbhip.so (C-ABI in include/obbhip.h).
 #include "ctx.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -45,6 +47,11 @@ int obb_ctx_create(int device, obb_ctx **out) {
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
+    for (int attempt = 0; attempt < 10 && (e != hipSuccess || ndev <= 0); ++attempt) {  // a GPU waking from its low-power state can miss the first probe
+        (void)hipGetLastError();
+        usleep(300 * 1000);
+        e = hipGetDeviceCount(&ndev);
+    }
     if (e != hipSuccess || ndev <= 0)
         return obb::set_error(nullptr, OBB_ERR_HIP, "obb_ctx_create: no HIP device visible (%s)", hipGetErrorString(e));
     if (device < 0 || device >= ndev)

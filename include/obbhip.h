@@ -178,6 +178,14 @@ int obb_results(obb_ctx *ctx, const float *det, const float *lb, int64_t n, floa
 int obb_probiou_loss(obb_ctx *ctx, const float *pred, const float *target, const float *weight, int64_t n, float target_scores_sum,
                      float *loss, float *grad_pred, obb_stream_t s);
 
+/* ------------------------------------------------------------------ f4: the training-set tiler's label assignment (Train_OBB.py:87-112) */
+/* For every (tile, label) pair: mask uint8[ntiles*n] = 1 when the label goes into the tile's label file (midpoint of corners 1 and 4
+ * inside the half-open tile AND >= min_fraction (object_boundary_threshold, :33) of its axis-aligned box inside), and then out
+ * double[(t*n + l)*8] = its corners shifted to the tile, clipped to [0, tile] and divided by the tile size.  labels double[n*8] pixel
+ * corners of one image; rects device int32[ntiles*4] (x, y, x2, y2) square tiles (the tiler only keeps full tiles, :83-84). */
+int obb_tile_labels(obb_ctx *ctx, const double *labels, int64_t n, const int32_t *rects, int32_t ntiles, double min_fraction, uint8_t *mask,
+                    double *out, obb_stream_t s);
+
 /* f1 (second slice): the other two terms of v8OBBLoss, forward and backward in one pass each.
  * DFL (ultralytics DFLoss inside RotatedBboxLoss): pred_dist float[n*4*reg_max] logits of the n matched anchors' four sides, target_ltrb
  * float[n*4] = bbox2dist(anchor, xyxy(target), reg_max - 1) (clamped to [0, reg_max - 1.01] here as the reference does), weight float[n]

@@ -45,6 +45,7 @@ SIGNATURES = {
     "obb_probiou_nms": [_V, _V, _V, C.c_int64, C.c_float, _V, _V, _V],
     "obb_results": [_V, _V, _V, C.c_int64, _V, _V, _V],
     "obb_probiou_loss": [_V, _V, _V, _V, C.c_int64, C.c_float, _V, _V, _V],
+    "obb_tile_labels": [_V, _V, C.c_int64, _V, C.c_int32, C.c_double, _V, _V, _V],
     "obb_dfl_loss": [_V, _V, _V, _V, C.c_int64, C.c_int32, C.c_float, _V, _V, _V],
     "obb_bce_loss": [_V, _V, _V, C.c_int64, C.c_float, _V, _V, _V],
 }

@@ -1070,6 +1070,37 @@ __global__ void k_add_offset(int32_t *v, int64_t n, int32_t add) {
     if (i < n) v[i] += add;
 }
 
+
+// ---- f4: label assignment of the training-set tiler (Train_OBB.py:87-112, one thread per (tile, label)): a label belongs to a tile when
+// the midpoint of its first and fourth corner lies inside the tile (half-open) and at least `thr` of its axis-aligned box does; its
+// corners are then shifted to the tile, clipped to [0, tile] and divided by the tile size.  Same float64 operations in the same order
+// as the pandas expressions, so the rows are bit-identical to the reference's label files before their text formatting.
+__global__ __launch_bounds__(256) void k_tile_labels(const double *__restrict__ labels, int64_t n, const int32_t *__restrict__ rects, int32_t ntiles,
+                                                    double thr, uint8_t *__restrict__ mask, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)ntiles * n) return;
+    const int64_t t = i / n, l = i - t * n;
+    const double x = (double)rects[4 * t], y = (double)rects[4 * t + 1];
+    const double ts = (double)(rects[4 * t + 2] - rects[4 * t]);
+    double px[4], py[4];
+    for (int k = 0; k < 4; ++k) { px[k] = labels[l * 8 + 2 * k]; py[k] = labels[l * 8 + 2 * k + 1]; }
+    const double cx = (px[0] + px[3]) / 2, cy = (py[0] + py[3]) / 2;
+    bool in = cx >= x && cx < x + ts && cy >= y && cy < y + ts;
+    if (in) {  // _cov_frac :60-70
+        const double bx1 = fmin(fmin(px[0], px[1]), fmin(px[2], px[3])), bx2 = fmax(fmax(px[0], px[1]), fmax(px[2], px[3]));
+        const double by1 = fmin(fmin(py[0], py[1]), fmin(py[2], py[3])), by2 = fmax(fmax(py[0], py[1]), fmax(py[2], py[3]));
+        const double ax = fmax(0.0, fmin(bx2, x + ts) - fmax(bx1, x)), ay = fmax(0.0, fmin(by2, y + ts) - fmax(by1, y));
+        const double inter = ax * ay, area = fmax(1e-6, (bx2 - bx1) * (by2 - by1));
+        in = inter / area >= thr;
+    }
+    mask[i] = in ? 1 : 0;
+    if (!in) return;
+    for (int k = 0; k < 4; ++k) {
+        out[i * 8 + 2 * k] = fmin(fmax(px[k] - x, 0.0), ts) / ts;
+        out[i * 8 + 2 * k + 1] = fmin(fmax(py[k] - y, 0.0), ts) / ts;
+    }
+}
+
 }  // namespace obb
 
 using namespace obb;
@@ -1368,6 +1399,18 @@ int obb_tile_postprocess(obb_ctx *ctx, const float *local_pts, const int32_t *cl
     OBB_REQUIRE(ctx, local_pts && cls && det_tile && rects && gboxes && angle && inside, "obb_tile_postprocess: NULL buffer");
     hipLaunchKernelGGL(k_tile_post, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, local_pts, cls, det_tile, n, rects,
                        margin, strike_cls, gboxes, angle, inside);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_tile_labels(obb_ctx *ctx, const double *labels, int64_t n, const int32_t *rects, int32_t ntiles, double min_fraction, uint8_t *mask,
+                    double *out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && ntiles >= 0, "obb_tile_labels: bad arguments");
+    if (n == 0 || ntiles == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, labels && rects && mask && out, "obb_tile_labels: NULL buffer");
+    const int64_t total = (int64_t)ntiles * n;
+    OBB_REQUIRE(ctx, cdiv(total, 256) < (1ll << 31), "obb_tile_labels: too many (tile, label) pairs");
+    hipLaunchKernelGGL(k_tile_labels, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, labels, n, rects, ntiles, min_fraction, mask, out);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

@@ -173,6 +173,11 @@ def _probiou_loss(pred: T, target: T, weight: Optional[T], target_scores_sum: fl
     _call("obb_probiou_loss", ctx(pred.device), _p(pred), _p(target), _p(weight), pred.shape[0], float(target_scores_sum), _p(loss), _p(grad_pred), _stream())
 
 
+@_op("tile_labels", ("mask", "out"))
+def _tile_labels(labels: T, rects: T, min_fraction: float, mask: T, out: T) -> None:
+    _call("obb_tile_labels", ctx(labels.device), _p(labels), labels.shape[0], _p(rects), rects.shape[0], float(min_fraction), _p(mask), _p(out), _stream())
+
+
 @_op("dfl_loss", ("loss", "grad_pred"))
 def _dfl_loss(pred_dist: T, target_ltrb: T, weight: Optional[T], reg_max: int, target_scores_sum: float, loss: T, grad_pred: T) -> None:
     _call("obb_dfl_loss", ctx(pred_dist.device), _p(pred_dist), _p(target_ltrb), _p(weight), target_ltrb.shape[0], int(reg_max), float(target_scores_sum),
@@ -492,6 +497,18 @@ def letterbox(image, x, y, x2, y2, imgsz):
     out = torch.empty((p["out_h"], p["out_w"], Cc), dtype=torch.uint8, device=img.device)
     _O.letterbox(img, int(x), int(y), int(x2), int(y2), int(imgsz), out)
     return out, p
+
+
+def tile_labels(labels, rects, min_fraction=0.1):
+    """Training-set tiler, label assignment (Train_OBB.py:87-112): labels float64 [n,8] pixel corners, rects int32 [T,4] square tiles ->
+    (mask uint8 [T,n], out float64 [T,n,8] = shifted / clipped / normalised corners where mask is set, zeros elsewhere)."""
+    lab = _chk(labels, torch.float64, "labels").reshape(-1, 8)
+    r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
+    mask = torch.zeros((r.shape[0], lab.shape[0]), dtype=torch.uint8, device=lab.device)
+    out = torch.zeros((r.shape[0], lab.shape[0], 8), dtype=torch.float64, device=lab.device)
+    if lab.shape[0] and r.shape[0]:
+        _O.tile_labels(lab, r, float(min_fraction), mask, out)
+    return mask, out
 
 
 def dfl_loss(pred_dist, target_ltrb, weight=None, target_scores_sum=1.0, reg_max=16):

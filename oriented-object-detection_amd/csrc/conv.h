@@ -69,7 +69,7 @@ std::vector<bf16_t> pack_conv_weights(const float *w_oihw, int cout, int cin, in
 
 int conv_ksteps(int ks, int CK);
 size_t conv_lds_bytes(const ConvLaunch &L);
-bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16 = false);
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16 = false, int TH = 0);
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st);
 
 }  // namespace obb

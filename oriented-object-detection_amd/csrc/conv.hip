@@ -607,14 +607,20 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
 //   TAIL = 4: the layer is followed by the head's plain 1x1 (64 -> <= 64 fp32 rows).  With the cout order chosen below a lane's two packed
 //   8-channel output pieces of a pixel are exactly its two B-operand fragments of that second GEMM (natural k order), so the tail runs
 //   straight from registers and the intermediate never touches LDS.
-template <bool F16, int TAIL>
+//   S = 2 (the stride-2 backbone convs with 64 input channels): the 27 x 27 x 64 input tile of a 13 x 13 output tile does not fit twice next
+//   to the weights, so a half-group takes a 4-row stripe of 13 outputs (9 x 27 input pixels, 35 KiB): one 16-pixel fragment per wave.  The
+//   k loop is then bound by LDS operand reads (4 weight + 1 activation fragment per 4 MFMAs) at about twice the MFMA time.
+//   TAIL = 16: the cv1 of the following C3k2 block (1x1 + SiLU, 16-bit output) behind the conv, from registers like the fp32 tail;
+//   the conv's own output is never written.
+template <bool F16, int TAIL, int S>
 __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
-    constexpr int MF = 3, NF = 4, PST = 144, KST = 18, T = 13, TWIN = T + 2, IN_PX = TWIN * TWIN, NCHUNK = IN_PX * 8, MAXLD = 8;
+    constexpr int MF = S == 1 ? 3 : 1, NF = 4, PST = 144, KST = 18, TH = S == 1 ? 13 : 4, T = 13, THIN = (TH - 1) * S + 3, TWIN = (T - 1) * S + 3;
+    constexpr int IN_PX = THIN * TWIN, NCHUNK = IN_PX * 8, MAXLD = 8, TF = TAIL > 0 ? 4 : 0;  // TF: cout fragments of the tail
     static_assert(NCHUNK <= MAXLD * 256, "staging plan");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) float s_bias[16 * NF];
-    __shared__ __attribute__((aligned(16))) float s_bias2[TAIL > 0 ? 16 * TAIL : 4];
+    __shared__ __attribute__((aligned(16))) float s_bias2[TAIL > 0 ? 64 : 4];
     const int tid = threadIdx.x, lane = tid & 63, htid = tid & 255;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave8 >> 2, hw = wave8 & 3;  // half-group, wave inside it
@@ -628,13 +634,18 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     char *w2lds = wlds + KST * NF * 1024;
     if (tid < 16 * NF) s_bias[tid] = P.bias[cb * 16 * NF + tid];
     if constexpr (TAIL > 0) {
-        if (tid < 16 * TAIL) s_bias2[tid] = P.bias2[tid];
-        // tail weights (2 k-steps x TAIL fragments), rows re-ordered to the natural cout order (fragment f, row r -> cout f*16 + r): a store
-        // instruction of the fp32 rows then covers 64 contiguous bytes per pixel (4 lanes x float4) instead of four 16-B pieces 64 B apart
-        for (int i = tid; i < 2 * TAIL * 64; i += 512) {
-            const int l = i & 63, f = (i >> 6) % TAIL, ks = i / (64 * TAIL);
-            const int r = l & 15, gq = l >> 4;
-            *reinterpret_cast<u32x4 *>(w2lds + i * 16) = reinterpret_cast<const u32x4 *>(P.w2pk)[((ks * TAIL + (r >> 2)) * 64) + (f * 4 + (r & 3)) + 16 * gq];
+        if (tid < 64) s_bias2[tid] = P.bias2[tid];
+        // tail weights (2 k-steps x 4 fragments).  fp32 head rows (TAIL = 4): rows re-ordered to the natural cout order (fragment f, row r ->
+        // cout f*16 + r), so that a store instruction covers 64 contiguous bytes per pixel (4 lanes x float4) instead of four 16-B pieces
+        // 64 B apart.  16-bit output (TAIL = 16): the order of the main weights below (two 16-B pieces per lane, 64 contiguous bytes per
+        // pixel and instruction).
+        for (int i = tid; i < 2 * TF * 64; i += 512) {
+            const int l = i & 63, f = (i >> 6) % TF, ks = i / (64 * TF);
+            const int r = l & 15, gq = l >> 4, gg = r >> 2, ii = r & 3;
+            int src;
+            if constexpr (TAIL == 4) src = ((ks * TF + gg) * 64) + (f * 4 + ii) + 16 * gq;
+            else src = ((ks * TF + (gg & 1) * 2 + (f & 1)) * 64) + ((f >> 1) * 2 + (gg >> 1)) * 4 + ii + 16 * gq;
+            *reinterpret_cast<u32x4 *>(w2lds + i * 16) = reinterpret_cast<const u32x4 *>(P.w2pk)[src];
         }
     }
     const int t0 = bx * P.tpw, t1 = min(t0 + P.tpw, P.ntiles);
@@ -647,8 +658,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     for (int mf = 0; mf < MF; ++mf) {
         const int p = (hw * MF + mf) * 16 + pl;
         const int ty = p / T, tx = p - ty * T;
-        const bool ok = p < T * T;
-        pixb[mf] = (ok ? (ty * TWIN + tx) * PST : 0) + g * 16;
+        const bool ok = p < TH * T;
+        pixb[mf] = (ok ? (ty * S * TWIN + tx * S) * PST : 0) + g * 16;
         ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
     }
     int ipos[MAXLD];
@@ -662,18 +673,31 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
         const int tx_i = t % P.tiles_x, r = t / P.tiles_x;
         const int ty_i = r % P.tiles_y;
         b = r / P.tiles_y;
-        oy0 = ty_i * T; ox0 = tx_i * T;
+        oy0 = ty_i * TH; ox0 = tx_i * T;
     };
     constexpr unsigned NOPIX = 0xffffffffu;
     u32x4 pre[MAXLD];
+    unsigned rel[MAXLD];  // byte offset of the thread's chunks relative to the tile's first input pixel (NOPIX for the surplus slots)
+#pragma unroll
+    for (int k = 0; k < MAXLD; ++k) {
+        const int cc = (htid + k * 256) & 7;
+        rel[k] = ipos[k] >= 0 ? (unsigned)(((ipos[k] >> 16) * P.Win + (ipos[k] & 0xffff)) * P.in_cs * 2) + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u : NOPIX;
+    }
     auto fetch_tile = [&](int t) {  // global -> registers, one whole input tile (zero padding through the descriptor's range check)
         int b, oy0, ox0;
         tile_origin(t, b, oy0, ox0);
         const bf16_t *base = (const bf16_t *)P.in + (int64_t)b * P.in_bs + P.in_co;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)P.in_span_bytes, 0x00020000);
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + THIN <= P.Hin && ix0 + TWIN <= P.Win) {  // (tile-uniform) no padding: one add per chunk
+            const unsigned tb = (unsigned)((iy0 * P.Win + ix0) * P.in_cs * 2);
+#pragma unroll
+            for (int k = 0; k < MAXLD; ++k) pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, rel[k] == NOPIX ? NOPIX : tb + rel[k], 0, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
-            const int gy = oy0 - 1 + (ipos[k] >> 16), gx = ox0 - 1 + (ipos[k] & 0xffff);
+            const int gy = iy0 + (ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
             const bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
             const int cc = (htid + k * 256) & 7;
             const unsigned off = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) + (unsigned)(cc >> P.in_bsh) * P.in_ps2 + (unsigned)(cc & P.in_bmask) * 16u : NOPIX;
@@ -738,25 +762,26 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
         }
     };
 
-    auto epilogue = [&](int t) {
-        int b, oy0, ox0;
-        tile_origin(t, b, oy0, ox0);
+    // What crosses the barrier between a tile's k loop and its stores: the packed 16-bit outputs (no tail) or the tail's accumulators.
+    // finish() runs right behind the k loop, in the same phase: bias, SiLU and packing of the main conv (and the tail's MFMAs) -- the k
+    // loop alone is shorter than the other half's store + stage + fetch phase, so this moves vector work from the longer phase to the
+    // shorter one; store_out() (tail bias / SiLU, address arithmetic, stores) stays in the next phase.
+    uint4 oc[TAIL == 0 ? MF : 1][2];
+    f32x4 acc2c[TAIL > 0 ? MF : 1][TAIL > 0 ? TF : 1];
+    auto finish = [&]() {
         float bias[NF * 4];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const float4 bv = *reinterpret_cast<const float4 *>(s_bias + (f >> 1) * 32 + g * 8 + (f & 1) * 4);
             bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
         }
-        hx8 w2[TAIL > 0 ? 2 * TAIL : 1];
+        hx8 w2[TAIL > 0 ? 2 * TF : 1];
         if constexpr (TAIL > 0) {
 #pragma unroll
-            for (int i = 0; i < 2 * TAIL; ++i) w2[i] = *reinterpret_cast<const hx8 *>(w2lds + (i * 64 + lane) * 16);
+            for (int i = 0; i < 2 * TF; ++i) w2[i] = *reinterpret_cast<const hx8 *>(w2lds + (i * 64 + lane) * 16);
         }
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-            const int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
-            const bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout);
-            const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
             float v[NF * 4];
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -772,33 +797,65 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
                 o[hh].x = HX<F16>::pack2(v[hh * 8 + 0], v[hh * 8 + 1]); o[hh].y = HX<F16>::pack2(v[hh * 8 + 2], v[hh * 8 + 3]);
                 o[hh].z = HX<F16>::pack2(v[hh * 8 + 4], v[hh * 8 + 5]); o[hh].w = HX<F16>::pack2(v[hh * 8 + 6], v[hh * 8 + 7]);
             }
+            if constexpr (TAIL == 0) { oc[mf][0] = o[0]; oc[mf][1] = o[1]; }
+            else {
+#pragma unroll
+                for (int f = 0; f < TF; ++f) acc2c[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    hx8 a2;
+                    __builtin_memcpy(&a2, &o[ks], 16);
+#pragma unroll
+                    for (int f = 0; f < TF; ++f) acc2c[mf][f] = HX<F16>::mfma(w2[ks * TF + f], a2, acc2c[mf][f]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_out = [&](int t) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
+            const bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout);
+            const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
             if constexpr (TAIL == 0) {
                 if (ok) {
                     bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const int occ = cb * 2 * NF + hh * 4 + g;  // 8-channel chunk index inside the output slice
-                        if (occ * 8 + 8 <= P.cout) *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = o[hh];
+                        if (occ * 8 + 8 <= P.cout) *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = oc[mf][hh];
                     }
                 }
-            } else {
-                f32x4 acc2[TAIL];
-#pragma unroll
-                for (int f = 0; f < TAIL; ++f) acc2[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    hx8 a2;
-                    __builtin_memcpy(&a2, &o[ks], 16);
-#pragma unroll
-                    for (int f = 0; f < TAIL; ++f) acc2[f] = HX<F16>::mfma(w2[ks * TAIL + f], a2, acc2[f]);
-                }
+            } else if constexpr (TAIL == 4) {
                 if (ok) {  // (2-D launch, 16-B aligned fp32 rows, cout2 a multiple of 4: checked by the host)
                     float *op = P.out2 + (int64_t)b * P.out2_bs + opix * P.out2_cs + P.out2_co + g * 4;
 #pragma unroll
-                    for (int f = 0; f < TAIL; ++f) {
+                    for (int f = 0; f < TF; ++f) {
                         const float4 bv = *reinterpret_cast<const float4 *>(s_bias2 + f * 16 + g * 4);
                         if (f * 16 + g * 4 + 4 <= P.cout2)
-                            *reinterpret_cast<float4 *>(op + f * 16) = make_float4(acc2[f][0] + bv.x, acc2[f][1] + bv.y, acc2[f][2] + bv.z, acc2[f][3] + bv.w);
+                            *reinterpret_cast<float4 *>(op + f * 16) = make_float4(acc2c[mf][f][0] + bv.x, acc2c[mf][f][1] + bv.y, acc2c[mf][f][2] + bv.z, acc2c[mf][f][3] + bv.w);
+                    }
+                }
+            } else {  // + bias, SiLU, 16 bit -> the tail's own output slice
+                float v2[16];
+#pragma unroll
+                for (int f = 0; f < TF; ++f) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(s_bias2 + (f >> 1) * 32 + g * 8 + (f & 1) * 4);
+                    v2[f * 4 + 0] = silu_f(acc2c[mf][f][0] + bv.x); v2[f * 4 + 1] = silu_f(acc2c[mf][f][1] + bv.y);
+                    v2[f * 4 + 2] = silu_f(acc2c[mf][f][2] + bv.z); v2[f * 4 + 3] = silu_f(acc2c[mf][f][3] + bv.w);
+                }
+                if (ok) {
+                    bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        uint4 o2;
+                        o2.x = HX<F16>::pack2(v2[hh * 8 + 0], v2[hh * 8 + 1]); o2.y = HX<F16>::pack2(v2[hh * 8 + 2], v2[hh * 8 + 3]);
+                        o2.z = HX<F16>::pack2(v2[hh * 8 + 4], v2[hh * 8 + 5]); o2.w = HX<F16>::pack2(v2[hh * 8 + 6], v2[hh * 8 + 7]);
+                        const int occ = hh * 4 + g;
+                        if (occ * 8 + 8 <= P.cout2) *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = o2;
                     }
                 }
             }
@@ -806,16 +863,16 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
         }
     };
 
-    // phase q of a half (q = p - h): 0 = stage tile 0; odd = k loop of tile q/2; even = store tile q/2 - 1, stage tile q/2, fetch tile q/2 + 1
+    // phase q of a half (q = p - h): 0 = stage tile 0; odd = k loop + finish of tile q/2; even = store tile q/2 - 1, stage tile q/2, fetch tile q/2 + 1
     STAMP_INIT  // (diagnostic build: 0 barrier wait, 1 epilogue, 2 tile copy to LDS incl. the wait for its loads, 3 k loop, 4 fetch issue)
     for (int p = 0; p < np; ++p) {
         const int q = p - h;
         if (q >= 0) {
             const int i = q >> 1;
             if (q & 1) {
-                if (i < n_h) { kloop(); STAMP(3) STAMP_TILE }
+                if (i < n_h) { kloop(); finish(); STAMP(3) STAMP_TILE }
             } else {
-                if (i >= 1 && i - 1 < n_h) { epilogue(t0 + h + 2 * (i - 1)); STAMP(1) }
+                if (i >= 1 && i - 1 < n_h) { store_out(t0 + h + 2 * (i - 1)); STAMP(1) }
                 if (i < n_h) {
                     store_tile();
                     STAMP(2)
@@ -862,6 +919,8 @@ ConvTiling plan_conv(int ks, int stride, int cin, int cout, int Hout, int Wout, 
     if (stride == 1 && t.MF == 3 && (cin == 32 || cin == 64) && (t.NF == 2 || t.NF == 1)) t.CK = cin;
     // 64 -> 64-cout groups: the same single-stage packing, run by k_conv3_pair (two half-groups per CU sharing the resident weights)
     if (pair && stride == 1 && t.MF == 3 && cin == 64 && t.NF == 4) t.CK = 64;
+    // stride 2, 64 input channels: 4-row stripes of 13 outputs per half-group (one fragment per wave), same packing
+    if (pair && stride == 2 && cin == 64 && t.NF == 4 && Wout % 13 == 0 && Hout >= 4) { t.TH = 4; t.TW = 13; t.MF = 1; t.CK = 64; }
     return t;
 }
 
@@ -900,10 +959,11 @@ static bool conv_wres(const ConvLaunch &L) { return L.ks == 3 && L.CK > 16; }
 static int tail_nf(int cout2);
 // k_conv3_pair's shapes (plan_conv gives them CK = 64): everything else with CK = 64 stays on the one-group WRES form of k_conv_igemm
 static bool conv_pair(const ConvLaunch &L) {
-    return L.ks == 3 && L.stride == 1 && L.MF == 3 && L.NF == 4 && L.CK == 64 && L.cin == 64 && L.TH == 13 && L.TW == 13 && !L.in_u8 && !L.out_f32 &&
-           !L.res.p && L.up_c == 0 && L.cout % 64 == 0 &&
-           (L.tail_cout == 0 || (!L.tail_act16 && tail_nf(L.tail_cout) == 4 && L.cout == 64 && L.tail_cout % 4 == 0 && L.tail_out_hw == 0 &&
-                                 ((L.tail_out.cs | L.tail_out.co) & 3) == 0));
+    if (L.ks != 3 || L.NF != 4 || L.CK != 64 || L.cin != 64 || L.TW != 13 || L.in_u8 || L.out_f32 || L.res.p || L.up_c != 0 || L.cout % 64) return false;
+    if (L.stride == 1)
+        return L.MF == 3 && L.TH == 13 && (L.tail_cout == 0 || (!L.tail_act16 && tail_nf(L.tail_cout) == 4 && L.cout == 64 && L.tail_cout % 4 == 0 && L.tail_out_hw == 0 &&
+                                                                ((L.tail_out.cs | L.tail_out.co) & 3) == 0));
+    return L.stride == 2 && L.MF == 1 && L.TH == 4 && (L.tail_cout == 0 || (L.tail_act16 && L.tail_cout == 64 && L.cout == 64));
 }
 
 // LDS layout: [input tile (one channel stage) | weights of the stage].  The epilogue's output staging starts at offset 0; for
@@ -929,9 +989,10 @@ size_t conv_lds_bytes(const ConvLaunch &L) {
     return conv_main_lds(L) + t;
 }
 
-bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16) {
+bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16, int TH) {
     if (cout1 != 16 * NF || cout2 < 1 || cout2 > 64) return false;
     const int nf2 = tail_nf(cout2);
+    if (act16 && ks == 3 && MF == 1 && NF == 4 && TH == 4) return cout2 == 64;  // k_conv3_pair, stride-2 stripes
     if (act16) return ks == 3 && MF == 3 && (NF == 2 || NF == 4) && nf2 == NF && cout2 == 16 * nf2;  // whole 16-bit rows of the staging area
     return (ks == 3 && MF == 3 && NF == 4 && nf2 == 4) || (ks == 3 && MF == 3 && NF == 1 && nf2 == 1) || (ks == 1 && MF == 2 && NF == 4 && nf2 == 1);
 }
@@ -1105,7 +1166,7 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     P.w2pk = L.tail_wpk; P.bias2 = L.tail_bias; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs;
     P.out2_co = L.tail_out.co; P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.kst2 = conv_ksteps(1, 16 * L.NF);
     P.w2_off = (int)conv_main_lds(L);
-    if (L.tail_cout > 0 && (!conv_tail_supported(L.ks, L.MF, L.NF, L.cout, L.tail_cout, L.tail_act16) || !L.tail_wpk || !L.tail_bias || (!L.tail_act16 && !L.tail_out.p))) return hipErrorInvalidValue;
+    if (L.tail_cout > 0 && (!conv_tail_supported(L.ks, L.MF, L.NF, L.cout, L.tail_cout, L.tail_act16, L.TH) || !L.tail_wpk || !L.tail_bias || (!L.tail_act16 && !L.tail_out.p))) return hipErrorInvalidValue;
 
     int cin_eff = L.in_u8 ? 8 : L.cin;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;
@@ -1118,7 +1179,7 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
         if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = (unsigned)span;
         P.w_bytes = (unsigned)wb;
-        if (conv_wres(L) && (L.stride != 1 || L.MF != 3 || L.CK != L.cin || (L.cin != 32 && L.cin != 64) || L.in_u8 || L.out_f32 || L.up_c > 0)) return hipErrorInvalidValue;
+        if (conv_wres(L) && !conv_pair(L) && (L.stride != 1 || L.MF != 3 || L.CK != L.cin || (L.cin != 32 && L.cin != 64) || L.in_u8 || L.out_f32 || L.up_c > 0)) return hipErrorInvalidValue;
     }
     int TWin = (L.TW - 1) * L.stride + L.ks;
     P.inv_twin = 1.0f / (float)TWin;
@@ -1150,8 +1211,12 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
             hipLaunchKernelGGL(kernel, grid, dim3(512), lds, st, P);
             return hipGetLastError();
         };
-        if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 4>) : go(k_conv3_pair<false, 4>);
-        return L.f16 ? go(k_conv3_pair<true, 0>) : go(k_conv3_pair<false, 0>);
+        if (L.stride == 2) {
+            if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 16, 2>) : go(k_conv3_pair<false, 16, 2>);
+            return L.f16 ? go(k_conv3_pair<true, 0, 2>) : go(k_conv3_pair<false, 0, 2>);
+        }
+        if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 4, 1>) : go(k_conv3_pair<false, 4, 1>);
+        return L.f16 ? go(k_conv3_pair<true, 0, 1>) : go(k_conv3_pair<false, 0, 1>);
     }
     // tiles per workgroup: keep >= ~8 groups per CU in flight, walk up to 8 consecutive tiles per group beyond that
     static const int tpw_max = getenv("OBB_TPW") ? atoi(getenv("OBB_TPW")) : 8;

@@ -249,7 +249,7 @@ struct Builder {
         if (r->g != 1 || r2->g != 1 || r->k != 3 || r2->k != 1 || r2->s != 1 || !r2->act || !r->act || r2->c1 != r->c2) return false;
         int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
         ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo, M.o.pair);
-        return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true);
+        return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true, t.TH);
     }
 
     // true if model.0 -> model.1 -> model.2.cv1 can run as ONE launch (front.hip): the n-scale widths on tiles whose sides are multiples of 52

@@ -122,25 +122,34 @@ def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
 
 
 def test_pair_kernel_matches_staged_kernel(ops, net_n):
-    """k_conv3_pair (64 -> 64-cout 3x3 convs of the head's box branch: weights resident in LDS, two half-groups per workgroup, all 64 input
-    channels in one k loop, the fp32 tail straight from registers) against k_conv_igemm on the same layers (four 16-channel stages): the k
-    sums are split differently, so 16-bit values flip by an ulp here and there; the fp32 box logits stay within the fused-form tolerance."""
+    """k_conv3_pair (3x3 convs with 64 input channels and 64-cout groups: weights resident in LDS, two half-groups per workgroup, all 64 input
+    channels in one k loop, tails straight from registers; stride 1 on 13 x 13 tiles, stride 2 on 4-row stripes) against k_conv_igemm on
+    the same layers (four 16-channel stages): the k sums are split differently, so 16-bit values flip by an ulp here and there.  model.4.cv1
+    (stride-2 conv + its fused 1x1, identical inputs) is held to 4 ulps; layers further down see propagated flips and are held
+    statistically; the fp32 box logits stay within the fused-form tolerance."""
     B, h, w = 3, 416, 416
     x = torch.as_tensor(_tiles(77, B, h, w)).cuda()
+    names = ("model.4.cv1", "model.17", "model.23.cv2.0.0")
     ops.model_load(net_n.to_blob(), precision=net_n.prec, pair=False)
-    assert not any("CK64" in l and "cv2.0.0" in l for l in ops.debug_plan(h, w))
+    assert not any("CK64" in l and ("cv2.0.0" in l or "model.3+" in l) for l in ops.debug_plan(h, w))
     ref_head = ops.forward(x).clone()
-    ref = ops.debug_activation("model.23.cv2.0.0", B, h, w).clone().float()
+    ref = {n: ops.debug_activation(n, B, h, w).clone().float() for n in names}
     ops.model_load(net_n.to_blob(), precision=net_n.prec)
-    assert any("CK64" in l and "cv2.0.0" in l for l in ops.debug_plan(h, w))
+    plan = ops.debug_plan(h, w)
+    assert any("CK64" in l and "cv2.0.0" in l for l in plan) and any("model.3+model.4.cv1" in l and "TH4" in l for l in plan) and any("model.17" in l and "TH4" in l for l in plan), plan
     head = ops.forward(x)
-    got = ops.debug_activation("model.23.cv2.0.0", B, h, w).float()
-    torch.cuda.synchronize()
-    ulp = (2.0 ** -10 if net_n.prec == "f16" else 2.0 ** -7) * torch.maximum(ref.abs(), torch.tensor(0.25, device="cuda"))
-    d = (got - ref).abs()
-    assert float((d / ulp).max()) <= 2.0 and float((d > 0).float().mean()) < 0.05, (float((d / ulp).max()), float((d > 0).float().mean()))
+    u = 2.0 ** -10 if net_n.prec == "f16" else 2.0 ** -7
+    for n in names:
+        got = ops.debug_activation(n, B, h, w).float()
+        d = (got - ref[n]).abs()
+        ulps = d / (u * torch.maximum(ref[n].abs(), torch.tensor(0.25, device="cuda")))
+        print(n, "max ulps", float(ulps.max()), "fraction differing", float((d > 0).float().mean()), "mean |d|", float(d.mean()))
+        if n == "model.4.cv1":
+            assert float(ulps.max()) <= 4.0 and float((d > 0).float().mean()) < 0.05  # (a flipped conv output moves the 1x1 behind it by another ulp or two)
+        else:
+            assert float(d.mean()) < (5e-3 if net_n.prec == "f16" else 5e-2) and float(d.max()) < (0.25 if net_n.prec == "f16" else 1.5)
     dh = (head[..., :77] - ref_head[..., :77]).abs()
-    assert float(dh.max()) < (0.25 if net_n.prec == "f16" else 2.0) and float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), (float(dh.max()), float(dh.mean()))
+    assert float(dh.max()) < (0.3 if net_n.prec == "f16" else 2.0) and float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), (float(dh.max()), float(dh.mean()))
 
 
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
@@ -180,11 +189,11 @@ def test_cv1_behind_stride2_conv(ops, net_n, h, w, B):
     """model.1 / model.3 (3x3 stride 2) run the cv1 of the following C3k2 block on their staged output tile (their own output tensor
     is never written): same 16-bit rounding of the intermediate, same k order -> identical activations and head."""
     x = torch.as_tensor(_tiles(23 + h, B, h, w)).cuda()
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail16=False)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, tail16=False, pair=False)
     assert not any("+model.2.cv1" in l for l in ops.debug_plan(h, w))
     ref_head = ops.forward(x).clone()
     ref = {n: ops.debug_activation(n, B, h, w).clone() for n in ("model.2.cv1", "model.4.cv1")}
-    ops.model_load(net_n.to_blob(), precision=net_n.prec, front=False)  # (the one-launch front has its own test: different rounding points)
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, front=False, pair=False)  # (front and the pair kernel have their own tests: different rounding points / k order)
     plan = ops.debug_plan(h, w)
     fused = [l for l in plan if "model.1+model.2.cv1" in l or "model.3+model.4.cv1" in l]
     assert len(fused) == (2 if (h, w) == (416, 416) else 0), plan   # 13x13 output tiles only (every level of a full 416-px tile)

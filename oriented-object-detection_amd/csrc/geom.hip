@@ -365,78 +365,78 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const BoxMeta *__restrict_
     members[atomicAdd(&cursor[grid_cell(m, *info, cx, cy)], 1)] = (int32_t)i;
 }
 
-// thread = box j (sorted position).  Small j: small partners i < j in the 3 x 3 cells around it.  Every j: the large rows (a small j takes
-// each large row, a large j the large rows before it, so every pair with a large member is seen once).  Two phases per round, as in
-// k_nms_mask: every lane runs up to kGridRound cheap class + envelope tests of its row and queues the survivors in LDS; then the whole
-// workgroup clips the queued pairs, one per lane (the exact IoU is ~100x a cheap test and would otherwise run in one lane of a wave).
+// WAVE = box j (sorted position).  Small j: small partners i < j in the 3 x 3 cells around it.  Every j: the large rows (a small j takes
+// each large row, a large j the large rows before it, so every pair with a large member is seen once).  The 64 lanes walk a cell's member
+// list together (class + envelope test each); survivors are compacted into the wave's LDS queue (ballot + prefix count, no atomics) and
+// clipped 64 at a time, one pair per lane: the exact IoU is ~100x a cheap test and must not run in one lane of a wave, and on dense maps
+// a box has hundreds of candidates, which a thread per box would walk serially.  The queue carries over from box to box.
 // Edge (lo, hi) when IoU(lo, hi) >= thr, the earlier row always the first operand (as k_nms_mask evaluates it).
-static constexpr int kGridRound = 16;
 __global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ sboxes, const int32_t *__restrict__ scls, const BoxMeta *__restrict__ meta, int64_t n,
                                                    double thr, const GridInfo *__restrict__ info, const int32_t *__restrict__ start,
                                                    const int32_t *__restrict__ members, const int32_t *__restrict__ large,
                                                    unsigned long long *__restrict__ edges, unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
-    __shared__ unsigned long long queue[256 * kGridRound];
-    __shared__ int qn;
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long queue[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridInfo g = *info;
-    BoxMeta mj;
-    mj.x0 = 1.0; mj.x1 = -1.0; mj.y0 = mj.y1 = 0.0;
-    int cj = -1;
-    if (j < n) { mj = meta[j]; cj = scls[j]; }
-    const bool valid = mj.x0 <= mj.x1;
-    const bool j_large = valid && grid_is_large(mj, g);
-    int cx = 0, cy = 0;
-    if (valid) grid_cell(mj, g, cx, cy);
-    int ph = !valid ? 10 : (j_large ? 9 : 0), cur = 0, end = 0;
-    const int32_t *src = members;
-    bool in_large = false;
-    auto advance = [&]() -> bool {  // true when src[cur] is the next candidate
-        while (cur >= end) {
-            if (ph >= 10) return false;
-            if (ph < 9) {
-                const int yy = cy - 1 + ph / 3, xx = cx - 1 + ph % 3;
-                ++ph;
-                if (yy < 0 || yy >= g.gh || xx < 0 || xx >= g.gw) continue;
-                const int c = yy * g.gw + xx;
-                cur = start[c]; end = start[c + 1];
-            } else { ph = 10; cur = 0; end = g.n_large; src = large; in_large = true; }
-        }
-        return true;
-    };
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
-    for (;;) {
-        int tests = 0;
-        while (tests < kGridRound && advance()) {
-            const int i = src[cur++];
-            ++tests;
-            const bool take = in_large ? (i != (int)j && (!j_large || i < (int)j)) : i < (int)j;
-            if (take && scls[i] == cj && meta_overlap(meta[i], mj)) {
-                const unsigned long long lo = i < (int)j ? (unsigned long long)i : (unsigned long long)j, hi = i < (int)j ? (unsigned long long)j : (unsigned long long)i;
-                queue[atomicAdd(&qn, 1)] = (lo << 32) | hi;
-            }
-        }
-        const int more = advance() ? 1 : 0;
-        __syncthreads();
-        const int nq = qn;
-        for (int e = threadIdx.x; e < nq; e += 256) {
-            const unsigned long long pr = queue[e];
+    unsigned long long *q = queue[wave];
+    int qn = 0;  // wave-uniform fill of the queue (< 64 between pushes)
+    auto clip64 = [&](int cnt) {  // clips the last `cnt` (<= 64) queued pairs, one per lane
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const unsigned long long pr = q[qn - cnt + lane];
             const int64_t lo = (int64_t)(pr >> 32), hi = (int64_t)(pr & 0xffffffffull);
-            P2 p[4], q[4];
+            P2 a[4], b[4];
             for (int k = 0; k < 4; ++k) {
-                p[k].x = sboxes[lo * 8 + 2 * k]; p[k].y = sboxes[lo * 8 + 2 * k + 1];
-                q[k].x = sboxes[hi * 8 + 2 * k]; q[k].y = sboxes[hi * 8 + 2 * k + 1];
+                a[k].x = sboxes[lo * 8 + 2 * k]; a[k].y = sboxes[lo * 8 + 2 * k + 1];
+                b[k].x = sboxes[hi * 8 + 2 * k]; b[k].y = sboxes[hi * 8 + 2 * k + 1];
             }
-            if (poly_iou_core(p, q) >= thr) {
+            if (poly_iou_core(a, b) >= thr) {
                 const unsigned int slot = atomicAdd(edge_count, 1u);
                 if (slot < edge_cap) edges[slot] = pr;
             }
         }
-        const int any = __syncthreads_or(more);
-        if (threadIdx.x == 0) qn = 0;
-        if (!any) break;
-        __syncthreads();
+        qn -= cnt;
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int64_t j = (int64_t)blockIdx.x * 4 + wave; j < n; j += (int64_t)gridDim.x * 4) {
+        const BoxMeta mj = meta[j];
+        if (!(mj.x0 <= mj.x1)) continue;
+        const int cj = scls[j];
+        const bool j_large = grid_is_large(mj, g);
+        int cx = 0, cy = 0;
+        grid_cell(mj, g, cx, cy);
+        for (int ph = j_large ? 9 : 0; ph < 10; ++ph) {  // 9 cells (small j only), then the large rows
+            int cur, end;
+            const int32_t *src;
+            if (ph < 9) {
+                const int yy = cy - 1 + ph / 3, xx = cx - 1 + ph % 3;
+                if (yy < 0 || yy >= g.gh || xx < 0 || xx >= g.gw) continue;
+                const int c = yy * g.gw + xx;
+                cur = start[c]; end = start[c + 1]; src = members;
+            } else { cur = 0; end = g.n_large; src = large; }
+            for (int base = cur; base < end; base += 64) {
+                const int m = base + lane;
+                bool pass = false;
+                int i = -1;
+                if (m < end) {
+                    i = src[m];
+                    const bool take = ph == 9 ? (i != (int)j && (!j_large || i < (int)j)) : i < (int)j;
+                    pass = take && scls[i] == cj && meta_overlap(meta[i], mj);
+                }
+                const unsigned long long bal = __ballot(pass);
+                if (bal) {
+                    if (pass) {
+                        const unsigned long long lo = i < (int)j ? (unsigned long long)i : (unsigned long long)j, hi = i < (int)j ? (unsigned long long)j : (unsigned long long)i;
+                        q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (lo << 32) | hi;
+                    }
+                    qn += __popcll(bal);
+                    if (qn >= 64) clip64(64);
+                }
+            }
+        }
     }
+    if (qn > 0) clip64(qn);
 }
 
 // One wave per 64x64 block of the (row i, col j>i) pair matrix.  Phase 1: every lane runs the 64 cheap
@@ -1303,7 +1303,7 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
             hipLaunchKernelGGL(k_grid_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, ginfo, hist, large);
             hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, ncell, start, hist);
             hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist, members);
-            hipLaunchKernelGGL(k_grid_pairs, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const double *)sboxes, (const int32_t *)scls, (const BoxMeta *)meta, n,
+            hipLaunchKernelGGL(k_grid_pairs, dim3((unsigned)std::min<int64_t>(cdiv(n, 4), 8192)), dim3(256), 0, st, (const double *)sboxes, (const int32_t *)scls, (const BoxMeta *)meta, n,
                                thr, (const GridInfo *)ginfo, (const int32_t *)start, (const int32_t *)members, (const int32_t *)large, edges, ecount, cap);
         } else {
             hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,

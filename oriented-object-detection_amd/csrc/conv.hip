@@ -612,10 +612,14 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
 //   k loop is then bound by LDS operand reads (4 weight + 1 activation fragment per 4 MFMAs) at about twice the MFMA time.
 //   TAIL = 16: the cv1 of the following C3k2 block (1x1 + SiLU, 16-bit output) behind the conv, from registers like the fp32 tail;
 //   the conv's own output is never written.
-template <bool F16, int TAIL, int S>
+//   NF = 5 (no tail, stride 1): two sibling convs on the same input merged along cout, 64 + 16 channels (the first convs of the head's box
+//   and angle branches at P3): the fifth fragment holds couts 64 + g*4 + i, stored as one 8-byte piece per lane (32 contiguous bytes per
+//   pixel); its weights come from the second 64-cout block of the standard packing.
+template <bool F16, int TAIL, int S, int NF = 4>
 __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     typedef typename HX<F16>::vec8 hx8;
-    constexpr int MF = S == 1 ? 3 : 1, NF = 4, PST = 144, KST = 18, TH = S == 1 ? 13 : 4, T = 13, THIN = (TH - 1) * S + 3, TWIN = (T - 1) * S + 3;
+    static_assert(NF == 4 || (NF == 5 && TAIL == 0 && S == 1), "merged 80-cout form: plain stride-1 layers only");
+    constexpr int MF = S == 1 ? 3 : 1, PST = 144, KST = 18, TH = S == 1 ? 13 : 4, T = 13, THIN = (TH - 1) * S + 3, TWIN = (T - 1) * S + 3;
     constexpr int IN_PX = THIN * TWIN, NCHUNK = IN_PX * 8, MAXLD = 8, TF = TAIL > 0 ? 4 : 0;  // TF: cout fragments of the tail
     static_assert(NCHUNK <= MAXLD * 256, "staging plan");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -715,12 +719,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     {   // the resident weight block of this cout group, rows re-ordered so that value (f, i) of lane group g is cout
         // (f >> 1) * 32 + g * 8 + (f & 1) * 4 + i: a lane's two 16-B output pieces then sit 64 B apart and the four lanes of a pixel write
         // 64 contiguous bytes per store instruction; the same order is the natural k order of the tail's B operand
-        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(P.wpk) + (size_t)cb * (KST * NF * 64);
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(P.wpk) + (size_t)cb * (KST * 4 * 64);  // (the packing has 4 fragments per 64-cout block)
         for (int i = tid; i < KST * NF * 64; i += 512) {
-            const int l = i & 63, f = (i >> 6) & 3, ks = i >> 8;
+            const int l = i & 63, f = (i >> 6) % NF, ks = i / (64 * NF);
             const int r = l & 15, gq = l >> 4, gg = r >> 2, ii = r & 3;
-            const int fs = (gg & 1) * 2 + (f & 1), rs = ((f >> 1) * 2 + (gg >> 1)) * 4 + ii;
-            *reinterpret_cast<u32x4 *>(wlds + i * 16) = wsrc[((ks * NF + fs) * 64) + rs + 16 * gq];
+            int src;
+            if (f < 4) src = ((ks * 4 + (gg & 1) * 2 + (f & 1)) * 64) + ((f >> 1) * 2 + (gg >> 1)) * 4 + ii + 16 * gq;
+            else src = KST * 4 * 64 + ((ks * 4 + gg) * 64) + ii + 16 * gq;  // cout 64 + gg*4 + ii = fragment gg, row ii of the second block
+            *reinterpret_cast<u32x4 *>(wlds + i * 16) = wsrc[src];
         }
     }
     const bool do_act = P.act != 0;
@@ -767,12 +773,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
     // loop alone is shorter than the other half's store + stage + fetch phase, so this moves vector work from the longer phase to the
     // shorter one; store_out() (tail bias / SiLU, address arithmetic, stores) stays in the next phase.
     uint4 oc[TAIL == 0 ? MF : 1][2];
+    uint2 oc5[NF == 5 ? MF : 1];  // fifth fragment of the merged form
     f32x4 acc2c[TAIL > 0 ? MF : 1][TAIL > 0 ? TF : 1];
     auto finish = [&]() {
         float bias[NF * 4];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const float4 bv = *reinterpret_cast<const float4 *>(s_bias + (f >> 1) * 32 + g * 8 + (f & 1) * 4);
+            const float4 bv = *reinterpret_cast<const float4 *>(s_bias + (f < 4 ? (f >> 1) * 32 + g * 8 + (f & 1) * 4 : 64 + g * 4));
             bias[f * 4 + 0] = bv.x; bias[f * 4 + 1] = bv.y; bias[f * 4 + 2] = bv.z; bias[f * 4 + 3] = bv.w;
         }
         hx8 w2[TAIL > 0 ? 2 * TF : 1];
@@ -797,7 +804,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
                 o[hh].x = HX<F16>::pack2(v[hh * 8 + 0], v[hh * 8 + 1]); o[hh].y = HX<F16>::pack2(v[hh * 8 + 2], v[hh * 8 + 3]);
                 o[hh].z = HX<F16>::pack2(v[hh * 8 + 4], v[hh * 8 + 5]); o[hh].w = HX<F16>::pack2(v[hh * 8 + 6], v[hh * 8 + 7]);
             }
-            if constexpr (TAIL == 0) { oc[mf][0] = o[0]; oc[mf][1] = o[1]; }
+            if constexpr (TAIL == 0) {
+                oc[mf][0] = o[0]; oc[mf][1] = o[1];
+                if constexpr (NF == 5) { oc5[mf].x = HX<F16>::pack2(v[16], v[17]); oc5[mf].y = HX<F16>::pack2(v[18], v[19]); }
+            }
             else {
 #pragma unroll
                 for (int f = 0; f < TF; ++f) acc2c[mf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -825,8 +835,12 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
                     bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        const int occ = cb * 2 * NF + hh * 4 + g;  // 8-channel chunk index inside the output slice
+                        const int occ = cb * 8 + hh * 4 + g;  // 8-channel chunk index inside the output slice
                         if (occ * 8 + 8 <= P.cout) *reinterpret_cast<uint4 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3)) = oc[mf][hh];
+                    }
+                    if constexpr (NF == 5) {
+                        const int occ = 8 + (g >> 1);  // channels 64 + g*4 .. + 3: half of chunk 8 or 9
+                        if (occ * 8 + 8 <= P.cout) *reinterpret_cast<uint2 *>(obase + (int64_t)(occ >> P.out_bsh) * P.out_ps + ((occ & P.out_bmask) << 3) + (g & 1) * 4) = oc5[mf];
                     }
                 }
             } else if constexpr (TAIL == 4) {
@@ -959,7 +973,9 @@ static bool conv_wres(const ConvLaunch &L) { return L.ks == 3 && L.CK > 16; }
 static int tail_nf(int cout2);
 // k_conv3_pair's shapes (plan_conv gives them CK = 64): everything else with CK = 64 stays on the one-group WRES form of k_conv_igemm
 static bool conv_pair(const ConvLaunch &L) {
-    if (L.ks != 3 || L.NF != 4 || L.CK != 64 || L.cin != 64 || L.TW != 13 || L.in_u8 || L.out_f32 || L.res.p || L.up_c != 0 || L.cout % 64) return false;
+    if (L.ks != 3 || L.NF != 4 || L.CK != 64 || L.cin != 64 || L.TW != 13 || L.in_u8 || L.out_f32 || L.res.p || L.up_c != 0) return false;
+    if (L.cout == 80) return L.stride == 1 && L.MF == 3 && L.TH == 13 && L.tail_cout == 0;  // two merged siblings, 64 + 16 couts: one group of five fragments
+    if (L.cout % 64) return false;
     if (L.stride == 1)
         return L.MF == 3 && L.TH == 13 && (L.tail_cout == 0 || (!L.tail_act16 && tail_nf(L.tail_cout) == 4 && L.cout == 64 && L.tail_cout % 4 == 0 && L.tail_out_hw == 0 &&
                                                                 ((L.tail_out.cs | L.tail_out.co) & 3) == 0));
@@ -1195,16 +1211,18 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
     if (conv_pair(L)) {  // one 512-thread workgroup per CU, its two halves walking alternate tiles
+        const int nf5 = L.cout == 80 ? 1 : 0;
+        if (nf5) ncb = 1;
         const int64_t groups = std::max<int64_t>(1, 256 / ncb);
         P.tpw = (int)std::max<int64_t>(2, (ntiles + groups - 1) / groups);
         P.gx = (int)((ntiles + P.tpw - 1) / P.tpw); P.ncb = ncb;
-        const size_t lds = 2 * (size_t)P.act_bytes + (size_t)P.kst * L.NF * 1024 + (L.tail_cout > 0 ? 2 * 4 * 1024 : 0);
-        if (P.kst != 18 || P.nstage != 1 || lds > 152 * 1024) return hipErrorInvalidValue;
+        const size_t lds = 2 * (size_t)P.act_bytes + (size_t)P.kst * (L.NF + nf5) * 1024 + (L.tail_cout > 0 ? 2 * 4 * 1024 : 0);
+        if (P.kst != 18 || P.nstage != 1 || lds > 158 * 1024) return hipErrorInvalidValue;
         const dim3 grid((unsigned)((P.gx + 7) / 8 * 8 * ncb));
         auto go = [&](auto kernel) -> hipError_t {
             static std::vector<const void *> attr_set;  // (the four instantiations share one function-pointer type: keyed by address)
             if (std::find(attr_set.begin(), attr_set.end(), (const void *)kernel) == attr_set.end()) {
-                hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+                hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);  // + static bias arrays <= 160 KiB
                 if (e != hipSuccess) return e;
                 attr_set.push_back((const void *)kernel);
             }
@@ -1215,6 +1233,7 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
             if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 16, 2>) : go(k_conv3_pair<false, 16, 2>);
             return L.f16 ? go(k_conv3_pair<true, 0, 2>) : go(k_conv3_pair<false, 0, 2>);
         }
+        if (nf5) return L.f16 ? go(k_conv3_pair<true, 0, 1, 5>) : go(k_conv3_pair<false, 0, 1, 5>);
         if (L.tail_cout > 0) return L.f16 ? go(k_conv3_pair<true, 4, 1>) : go(k_conv3_pair<false, 4, 1>);
         return L.f16 ? go(k_conv3_pair<true, 0, 1>) : go(k_conv3_pair<false, 0, 1>);
     }

@@ -761,7 +761,10 @@ struct Builder {
             std::string p = "model.23.cv2." + std::to_string(i), p4 = "model.23.cv4." + std::to_string(i);
             // (only where a layer is one tile per image and therefore latency-bound: at the larger levels the padded second cout block costs
             //  more MFMA time than the saved launch and input read are worth -- measured)
-            const std::string mn = (c2 % 16 == 0 && c4 % 16 == 0 && Hs[i] * Ws[i] <= 256) ? merged_record(p + ".0", p4 + ".0") : std::string();
+            //  -- except where k_conv3_pair takes the merged 64 + 16 couts as ONE group of five fragments (64 input channels, 13 x 13 tiles):
+            //  no padded block there, and the feature map is read once instead of twice)
+            const bool pair80 = M.o.pair && !M.f32 && P.bufs[feats[i]].C == 64 && c2 == 64 && c4 == 16 && Hs[i] % 13 == 0 && Ws[i] % 13 == 0;
+            const std::string mn = (c2 % 16 == 0 && c4 % 16 == 0 && (Hs[i] * Ws[i] <= 256 || pair80)) ? merged_record(p + ".0", p4 + ".0") : std::string();
             if (err) return err;
             int t1, t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
             if (!mn.empty()) {  // box and angle branch start with a 3x3 conv on the same feature map: one launch, [t1 | u1] in 16-channel blocks

@@ -121,6 +121,24 @@ def test_front_kernel_matches_separate_launches(ops, h, w, B, ch):
     assert float(dh.max()) < 0.5 and float(dh.mean()) < 1e-2, (float(dh.max()), float(dh.mean()))
 
 
+def test_merged_sibling_convs_match_separate_launches(ops, net_n):
+    """hmerge: the first convs of the head's box and angle branches read the same feature map; at P5 (one tile per image) they run as one
+    80-cout k_conv_igemm launch, at P3 as ONE five-fragment group of k_conv3_pair.  Same k order as the separate launches -> identical."""
+    B, h, w = 3, 416, 416
+    x = torch.as_tensor(_tiles(19, B, h, w)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, hmerge=False)
+    assert not any("cv2.0.0|" in l or "cv2.2.0|" in l for l in ops.debug_plan(h, w))
+    ref = ops.forward(x).clone()
+    ref_a = {n: ops.debug_activation(n, B, h, w).clone() for n in ("model.23.cv2.0.0", "model.23.cv4.0.0", "model.23.cv4.2.0")}
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    plan = ops.debug_plan(h, w)
+    assert any("model.23.cv2.0.0|model.23.cv4.0.0" in l and "cout80" in l for l in plan) and any("model.23.cv2.2.0|model.23.cv4.2.0" in l for l in plan), plan
+    got = ops.forward(x)
+    for n, r in ref_a.items():
+        assert torch.equal(ops.debug_activation(n, B, h, w), r), n
+    assert torch.equal(got[..., :77], ref[..., :77])
+
+
 def test_pair_kernel_matches_staged_kernel(ops, net_n):
     """k_conv3_pair (3x3 convs with 64 input channels and 64-cout groups: weights resident in LDS, two half-groups per workgroup, all 64 input
     channels in one k loop, tails straight from registers; stride 1 on 13 x 13 tiles, stride 2 on 4-row stripes) against k_conv_igemm on

@@ -768,7 +768,7 @@ struct Builder {
             if (err) return err;
             int t1, t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
             if (!mn.empty()) {  // box and angle branch start with a 3x3 conv on the same feature map: one launch, [t1 | u1] in 16-channel blocks
-                int hb = buf(Hs[i], Ws[i], c2 + c4, p + ".t1u1", false, 16);
+                int hb = buf(Hs[i], Ws[i], c2 + c4, p + ".t1u1", false, pair80 ? 0 : 16);  // (the pair kernel reads whole 128-B pixel rows: plain NHWC there)
                 conv(mn, whole(feats[i]), Hs[i], Ws[i], whole(hb));
                 P.named[p + ".0"] = sub(hb, 0, c2);
                 P.named[p4 + ".0"] = sub(hb, c2, c4);

@@ -202,6 +202,19 @@ def test_concurrent_chains_and_rounds_match_small_batches(ops, net_n):
     assert torch.equal(big, small) and torch.equal(big2, small)
 
 
+@pytest.mark.parametrize("B", [5, 65, 300])
+def test_head_of_a_tile_does_not_depend_on_its_batch(ops, net_n, B):
+    """416-px tiles through the persistent kernels (k_front, k_conv3_pair: tiles dealt to workgroups and half-groups by index, odd counts,
+    one- and two-chain rounds): every tile's head must equal the head of that tile run alone, and a replay must reproduce it."""
+    x = torch.as_tensor(_tiles(B, B, 416, 416)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    got = ops.forward(x).clone()
+    again = ops.forward(x).clone()
+    for k in sorted({0, 1 % B, B // 2, B - 2, B - 1}):
+        assert torch.equal(ops.forward(x[k:k + 1].contiguous())[0], got[k]), k
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (416, 288, 2), (128, 128, 4)])
 def test_cv1_behind_stride2_conv(ops, net_n, h, w, B):
     """model.1 / model.3 (3x3 stride 2) run the cv1 of the following C3k2 block on their staged output tile (their own output tensor

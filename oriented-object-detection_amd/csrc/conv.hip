@@ -730,7 +730,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3_pair(const ConvParams P) {
         }
     }
     const bool do_act = P.act != 0;
-    const int cbase = cb * 16 * NF + g * 4 * NF;
     f32x4 acc[MF][NF];
 
     auto kloop = [&]() {

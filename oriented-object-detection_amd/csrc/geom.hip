@@ -16,7 +16,6 @@
 
 namespace obb {
 
-static constexpr int kWave = 64;
 
 // ------------------------------------------------------------------------------------------------ pair list / matrix
 

@@ -9,6 +9,7 @@ namespace obb {
 struct DwPwLaunch {
     TensorRef in, out;   // plain NHWC 16-bit tensors (out: 64 channels; unused when tail_cout > 0)
     TensorRef tail_out;  // fp32 rows of the head tensor (tail_cout > 0)
+    void *sink = nullptr;  // >= 1 KiB of device scratch: lanes of the tail without a cout store there (stores stay unconditional)
     const bf16_t *dw_w = nullptr;   // [9][cin] in the storage type
     const float *dw_b = nullptr;    // [cin]
     const bf16_t *pw_w = nullptr;   // pack_conv_weights(w, 64, cin, 1, {NF = 4, CK = cin})

@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct DwPwParams {
     const bf16_t *in; int64_t in_bs; int in_cs;
     bf16_t *out; int64_t out_bs; int out_cs;
-    float *out2; int64_t out2_bs; int out2_cs, out2_co, cout2;
+    float *out2; int64_t out2_bs; int out2_cs, out2_co, cout2; float *sink;
     const bf16_t *dww, *pww, *tlw;
     const float *dwb, *pwb, *tlb;
     int H, stripes_y, nstripes, spw;
@@ -161,15 +161,11 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
                 acc2 = HX<F16>::mfma(*reinterpret_cast<const hx8 *>(TL + (64 + lane) * 16), __builtin_bit_cast(hx8, y[1]), acc2);
                 const float4 tb = *reinterpret_cast<const float4 *>(s_tlb + g * 4);
                 const float v0 = acc2[0] + tb.x, v1 = acc2[1] + tb.y, v2 = acc2[2] + tb.z, v3 = acc2[3] + tb.w;
+                // one float4 per lane on every path (the host guarantees 16-B aligned rows and cout2 % 4 == 0): lanes beyond the last cout store
+                // into the sink, so the compiler can count the stores and the wait for the next stripe's prefetch leaves them in flight
                 float *op = P.out2 + (int64_t)b * P.out2_bs + pix * P.out2_cs + P.out2_co + g * 4;
-                if (g * 4 + 4 <= P.cout2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
-                    *reinterpret_cast<float4 *>(op) = make_float4(v0, v1, v2, v3);
-                } else {
-                    if (g * 4 + 0 < P.cout2) op[0] = v0;
-                    if (g * 4 + 1 < P.cout2) op[1] = v1;
-                    if (g * 4 + 2 < P.cout2) op[2] = v2;
-                    if (g * 4 + 3 < P.cout2) op[3] = v3;
-                }
+                if (g * 4 + 4 > P.cout2) op = P.sink + lane * 4;
+                *reinterpret_cast<float4 *>(op) = make_float4(v0, v1, v2, v3);
             }
         }
     }
@@ -186,7 +182,7 @@ bool dwpw_supported(int cin, int cout, int H, int W, int tail_cout) {
     if (cout != 64 || tail_cout < 0 || tail_cout > 16) return false;
     const bool shape = (cin == 64 && W == 52) || ((cin == 64 || cin == 128) && W == 26);
     if (!shape || H <= 0 || H % dwpw_rows(W)) return false;
-    return tail_cout == 0 || cin == 64;  // the branch's second pair (64 -> 64 -> nc) carries the tail
+    return tail_cout == 0 || (cin == 64 && tail_cout % 4 == 0);  // the branch's second pair (64 -> 64 -> nc) carries the tail (whole float4s per lane)
 }
 
 std::vector<bf16_t> pack_dwpw_tail(const float *w, int cout2, bool f16) {
@@ -215,11 +211,13 @@ hipError_t launch_dwpw(const DwPwLaunch &L, hipStream_t st) {
     DwPwParams P;
     P.in = (const bf16_t *)L.in.p + L.in.co; P.in_bs = L.in.bs; P.in_cs = L.in.cs;
     P.out = nullptr; P.out_bs = 0; P.out_cs = 0;
-    P.out2 = nullptr; P.out2_bs = 0; P.out2_cs = 0; P.out2_co = 0; P.cout2 = 0;
+    P.out2 = nullptr; P.out2_bs = 0; P.out2_cs = 0; P.out2_co = 0; P.cout2 = 0; P.sink = nullptr;
     P.dww = L.dw_w; P.dwb = L.dw_b; P.pww = L.pw_w; P.pwb = L.pw_b; P.tlw = L.tail_w; P.tlb = L.tail_b;
     if (L.tail_cout > 0) {
         if (!L.tail_out.p || !L.tail_w || !L.tail_b) return hipErrorInvalidValue;
         P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs; P.out2_co = L.tail_out.co; P.cout2 = L.tail_cout;
+        P.sink = (float *)L.sink;
+        if (!L.sink || (L.tail_cout & 3) || ((L.tail_out.cs | L.tail_out.co) & 3)) return hipErrorInvalidValue;  // float4 rows, sink for the surplus lanes
     } else {
         if (L.out.cpb || !L.out.p || (L.out.cs | L.out.co) & 7) return hipErrorInvalidValue;
         P.out = (bf16_t *)L.out.p + L.out.co; P.out_bs = L.out.bs; P.out_cs = L.out.cs;

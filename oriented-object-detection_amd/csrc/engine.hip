@@ -977,6 +977,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     hr.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
                     hr.bs = (int64_t)P.A * P.no_pad; hr.cs = P.no_pad; hr.co = op.out.co;
                     L.tail_out = hr;
+                    L.sink = (char *)M.lut_dev + 512;
                 } else L.out = tref(P, op.out, boff);
                 e = launch_dwpw(L, st);
                 break;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) {
             int idx = tid + k * 256;
-            prew[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wbase + (unsigned)(idx < nwchunk ? idx : nwchunk - 1) * 16u, 0, 0);
+            prew[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (P.dbg & 16) ? 0xffffffffu : wbase + (unsigned)(idx < nwchunk ? idx : nwchunk - 1) * 16u, 0, 0);
         }
     };
     auto store_w = [&]() {

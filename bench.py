@@ -14,10 +14,12 @@ scaling) and the survivors of all ranks are exchanged every step exactly as the 
 a launcher; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the ranks it is given.
 
 Prints ONE JSON line (rank 0).  Objects beside the contract fields:
-  "roofline"      MFMA roofline of the forward (algorithmic FLOPs / HIP-event time), plus "postproc": HBM-side figures of decode + NMS
-  "f32"           the same workload in fp32 arithmetic (obb_set_option precision 32 -- what the reference computes), with its own roofline
-                  (exact-f32 MFMA peak 157.3 TFLOP/s)
-  "also"          the other BASELINE configs timed the same way: dual-scale (configs[2]) and 4-channel input (configs[3], per GPU)
+  "roofline"      MFMA roofline of the forward (algorithmic FLOPs / HIP-event time) against the peak of the arithmetic the line ran in
+  "also"          the other BASELINE configs timed the same way in the headline's arithmetic: "dual_scale" (configs[2]) and "ch4"
+                  (configs[3], per GPU); and "f16": the opt-in 16-bit fast mode (fp16 storage, fp32 accumulate) on the same three
+                  workloads, each with its own roofline against the 2.5 PFLOP/s fp16 MFMA peak
+The headline runs in fp32 arithmetic (obb_set_option precision 32: exact-f32 MFMA, peak 157.3 TFLOP/s) because that is what the
+reference computes (Detect_OBB.py:79-83, half=False); --precision f16 / bf16 makes the 16-bit mode the headline instead.
   "cpu_baseline"  the CPU restatement of the same path (bounded sample; baseline only)
 """
 import argparse
@@ -45,9 +47,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("OBB_BENCH_BATCH", 1024)), help="tiles per GPU per step (SURVEY 8(d): B in {1, 16, 64, 256, 1024})")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="run the steps strictly one after the other (no forward / post-processing overlap)")
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f32"], help="arithmetic of the HEADLINE line (the f32 figure is reported beside it by default)")
+    ap.add_argument("--precision", default="f32", choices=["f16", "bf16", "f32"], help="arithmetic of the HEADLINE line (default fp32 = the reference's; the f16 figures are reported under also.f16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the f32 / dual-scale / 4-channel measurements beside the headline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dual-scale / 4-channel / f16 measurements beside the headline")
     ap.add_argument("--channels", type=int, default=3, choices=[3, 4], help="4 = BASELINE configs[3] as the headline: every step also builds the RGB + DT-edge "
                     "input of a 4-channel checkpoint from the BGR tiles (build_multich) before the forward")
     return ap.parse_args()
@@ -85,7 +87,7 @@ def cpu_baseline(budget_s=15.0):
     from oracle import geom as og
     og.merge_detections(dets, 0.4)
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": n / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{n} synthetic 416x416x3 tiles, one model call per tile (reference loop), torch-CPU fp32 + C geometry, {dt:.1f} s"}
 
 
@@ -172,18 +174,13 @@ def main():
                 self.ev.append((e0, e1))
             return head
 
-        def records(self, head):  # on s_post: decode -> Fast-NMS -> results -> border filter -> per-tile merge
+        def records(self, head):  # on s_post: decode -> Fast-NMS -> results -> border filter -> per-tile merge -> exchange records
             self.model._ensure_active()
             md = self.cfg.max_det
-            det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md)
-            valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
-            rows = torch.nonzero(valid).squeeze(1)
-            if not rows.numel():
-                return D.TileRecords.empty(dev)
-            d = det.reshape(-1, 7)[rows].contiguous()
-            slot = (rows // md).long()
-            _, pts = ops.results(d, None)
-            return D._tile_records(pts, d[:, 5].int().contiguous(), d[:, 4].contiguous(), self.tile_ids[slot].contiguous(), self.rects_dev, self.cfg, self.px)
+            det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md, zero=False)
+            margin = self.cfg.margin_for(self.px) if self.cfg.APPLY_BORDER_FILTER else 0
+            rec, _, n = ops.tile_survivors(det, cnt, None, self.tile_ids, self.rects_dev, margin, self.cfg.iou_threshold, self.cfg.strike_cls)
+            return D.TileRecords.from_packed(rec, n)  # packed rows + their count, both still on the device
 
     def measure(scales, steps, warmup, pipeline=True):
         """-> dict(dt, nrec, nmerged, fwd_ms per scale).  Two HIP streams, software-pipelined over steps: the forwards of step k+1 (whole
@@ -207,13 +204,13 @@ def main():
                     rec = sc.records(head)
                     if world > 1:
                         rec = DD.all_gather_records(rec)
-                    nrec += len(rec)
+                    nrec += len(rec)  # the one host read of this scale's step: the survivor count sizes the fusion launches
                     sets[sc.px] = D.records_to_detset(rec, sc.rects_dev, sc.cfg, sc.px)
                 fused = D.cross_scale_consensus_filter_device(sets) if len(scales) > 1 else sets[scales[0].px]  # Detect_OBB.py:290
-                merged, _ = D.merge_detections_device(fused, scales[0].cfg.iou_threshold)                    # :291
+                merged, _ = D.merge_detections_device(fused, scales[0].cfg.iou_threshold)                    # :291 (kept rows + device count)
                 done = torch.cuda.Event()
                 done.record()
-            return nrec, len(merged), done
+            return nrec, merged, done
 
         def run_steps(n, timed):
             cur = torch.cuda.current_stream()
@@ -246,7 +243,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nrec, nmerged = run_steps(steps, True)
+        nrec, merged = run_steps(steps, True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -255,21 +252,23 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        nmerged = len(merged)  # the final count is read once, outside the timed region
         return {"dt": dt, "nrec": nrec, "nmerged": nmerged, "fwd_ms": [float(np.mean([a.elapsed_time(b) for a, b in sc.ev])) for sc in scales]}
 
     def roofline(precision, flop_per_step, fwd_ms):
         ach = flop_per_step / (fwd_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision], "forward_ms": fwd_ms}
 
-    def profiled_traffic():
+    def profiled_traffic(precision, nt):
         """HBM bytes of one forward from the committed rocprofv3 PMC passes of this build (FETCH_SIZE x2 + WRITE_SIZE, collected at 256
-        tiles, see tools/profile_all.sh), scaled to this step's tiles; (None, None) if no profile is there."""
+        tiles, see tools/profile_all.sh), scaled to `nt` tiles; (None, None) if no profile of that arithmetic is there."""
         import re
-        for name in ("r02_forward_hbm_traffic_b256.txt", "r01_forward_hbm_traffic_b256.txt"):
+        stem = "forward_f32_hbm_traffic_b256.txt" if precision == "f32" else "forward_hbm_traffic_b256.txt"
+        for rnd in ("r03_", "r02_", "r01_"):
             try:
-                m = re.search(r"-> ([0-9.]+) MB / tile", open(os.path.join(ROOT, "profiles", name)).read(600))
+                m = re.search(r"-> ([0-9.]+) MB / tile", open(os.path.join(ROOT, "profiles", rnd + stem)).read(600))
                 if m:
-                    return float(m.group(1)) * 1e6 * B, "profiles/" + name
+                    return float(m.group(1)) * 1e6 * nt, "profiles/" + rnd + stem
             except OSError:
                 pass
         return None, None
@@ -280,16 +279,62 @@ def main():
         tile_ids = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
         return model, [Scale(model, 416, B, rank, rects, tile_ids, channels)]
 
+    KERNEL = {"f32": "k_conv_f32 family (whole forward, v_mfma_f32_16x16x4_f32)", "f16": "k_conv_igemm family (whole forward, v_mfma_f32_16x16x32_f16)",
+              "bf16": "k_conv_igemm family (whole forward, v_mfma_f32_16x16x32_bf16)"}
+
+    def run_single(precision, channels, steps, warmup):
+        """configs[1] (3 channels) / configs[3] per GPU (4 channels) in the given arithmetic -> (throughput dict, roofline dict)"""
+        model, scales = single_scale(precision, channels)
+        h = measure(scales, steps, warmup, args.pipeline)
+        flop = FLOP_PER_TILE if channels == 3 else FLOP_PER_TILE_4CH
+        rf = roofline(precision, B * flop, h["fwd_ms"][0])
+        traffic, src = profiled_traffic(precision, B) if channels == 3 else (None, None)
+        rf.update({"traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per tile x tiles per step)") if src else None,
+                   "kernel": KERNEL[precision]})
+        del scales
+        model.close()
+        return h, rf
+
+    def run_dual(precision, steps):
+        """BASELINE configs[2]: dual-scale (128 + 416) late fusion.  The virtual map of the B 416-px tiles (16 columns, stride 316) is scanned
+        at the 128-px scale as well (stride 98): both forwards, both per-tile paths, cross_scale_consensus_filter and the final merge inside
+        every step (Detect_OBB.py:277-291)"""
+        cols, rows_ = 16, (B + 15) // 16
+        Wm, Hm = (cols - 1) * 316 + 416, (rows_ - 1) * 316 + 416
+        c128, r128 = len(range(0, Wm - 127, 98)), len(range(0, Hm - 127, 98))  # full 128-px tiles only
+        n128 = c128 * r128
+        rects128 = np.zeros((n128, 4), np.int32)
+        for t in range(n128):
+            x, y = (t % c128) * 98, (t // c128) * 98
+            rects128[t] = (x, y, x + 128, y + 128)
+        m128 = YOLO(weights(3, 1), imgsz=128, precision=precision)
+        m416 = YOLO(weights(3, 0), imgsz=416, precision=precision)
+        sc = [Scale(m128, 128, n128, 7, rects128, torch.arange(n128, dtype=torch.int32, device=dev)),
+              Scale(m416, 416, B, 0, synthetic_rects(B), torch.arange(B, dtype=torch.int32, device=dev))]
+        r = measure(sc, steps, 2, args.pipeline)
+        flopd = n128 * FLOP_PER_TILE_128 + B * FLOP_PER_TILE
+        rf = roofline(precision, flopd, r["fwd_ms"][0] + r["fwd_ms"][1])
+        rf["by_scale"] = {"128": roofline(precision, n128 * FLOP_PER_TILE_128, r["fwd_ms"][0]), "416": roofline(precision, B * FLOP_PER_TILE, r["fwd_ms"][1])}
+        d = {"workload": "BASELINE configs[2]: dual-scale (128 + 416) 3ch late fusion: per step %d 128-px tiles + %d 416-px tiles of one %dx%d virtual map -> "
+                         "both forwards + decode + NMS + per-tile merges + cross_scale_consensus_filter + final merge" % (n128, B, Wm, Hm),
+             "value": B * steps / r["dt"], "unit": "416px-tile map areas/s (each with its %.1f 128-px tiles)" % (n128 / B), "dtype": precision,
+             "tiles_per_s_both_scales": (B + n128) * steps / r["dt"], "steps": steps, "ms_per_step": r["dt"] / steps * 1e3,
+             "forward_ms": {"128": r["fwd_ms"][0], "416": r["fwd_ms"][1]}, "roofline": rf,
+             "survivor_records_per_step": r["nrec"], "final_detections": r["nmerged"]}
+        del sc
+        m128.close()
+        m416.close()
+        return d
+
+    def run_ch4(precision, steps):
+        h4, rf4 = run_single(precision, 4, steps, 2)
+        return {"workload": "BASELINE configs[3] per GPU: build_multich (DT-edge channel) + 4-channel forward + the same post-processing",
+                "value": B * steps / h4["dt"], "unit": "tiles/s", "dtype": precision, "steps": steps, "ms_per_step": h4["dt"] / steps * 1e3, "roofline": rf4}
+
     # ------------------------------------------------------------------ headline: configs[1] (or configs[3] with --channels 4)
-    hmodel, hscales = single_scale(args.precision, args.channels)
-    h = measure(hscales, args.steps, args.warmup, args.pipeline)
+    h, rf = run_single(args.precision, args.channels, args.steps, args.warmup)
     out = None
     if rank == 0:
-        flop = FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH
-        rf = roofline(args.precision, B * flop, h["fwd_ms"][0])
-        traffic, src = profiled_traffic() if (args.channels == 3 and args.precision != "f32") else (None, None)
-        rf.update({"traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per tile x tiles per step)") if src else None,
-                   "kernel": "k_conv_f32 family (whole forward)" if args.precision == "f32" else "k_conv_igemm family (whole forward)"})
         out = {
             "metric": "416px tiles/sec (whole node), YOLOv11n-OBB %dch" % args.channels,
             "value": world * B * args.steps / h["dt"], "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,66 +345,29 @@ def main():
                                    ("YOLOv11n-OBB 4ch (RGB + DT-edge) 416x416 tiled inference, single-scale (BASELINE configs[3] per GPU): build_multich + "
                                     "forward + decode + ProbIoU NMS + border filter + per-tile merge + final polygon-IoU merge"),
                        "tiles_per_gpu_per_step": B, "step_pipelining": bool(args.pipeline), "nc": 12, "weights": "synthetic seeded, cls bias -8 (no checkpoint offline)",
+                       "arithmetic": {"f32": "fp32 weights / activations / accumulation end to end (what Detect_OBB.py computes with half=False)",
+                                      "f16": "fp16 storage, fp32 accumulate (opt-in fast mode)", "bf16": "bf16 storage, fp32 accumulate (opt-in fast mode)"}[args.precision],
                        "survivor_records_per_step": h["nrec"], "final_detections": h["nmerged"]},
             "roofline": rf,
         }
-    del hscales
-    hmodel.close()
 
     extras = not args.no_extras and world == 1
-    if extras and args.precision != "f32":
-        # ---------------------------------------------------------------- the same workload in the reference's own arithmetic (fp32)
-        m32, s32 = single_scale("f32", args.channels)
-        steps32 = max(3, args.steps // 2)
-        r = measure(s32, steps32, 2, args.pipeline)
-        if rank == 0:
-            flop = FLOP_PER_TILE if args.channels == 3 else FLOP_PER_TILE_4CH
-            rf = roofline("f32", B * flop, r["fwd_ms"][0])
-            rf.update({"traffic": None, "kernel": "k_conv_f32 family (whole forward, v_mfma_f32_16x16x4_f32)"})
-            out["f32"] = {"value": B * steps32 / r["dt"], "unit": "tiles/s", "dtype": "f32", "steps": steps32, "warmup": 2, "ms_per_step": r["dt"] / steps32 * 1e3,
-                          "roofline": rf, "survivor_records_per_step": r["nrec"], "final_detections": r["nmerged"],
-                          "note": "fp32 weights / activations / accumulation end to end (obb_set_option precision 32): what Detect_OBB.py computes with half=False"}
-        del s32
-        m32.close()
     if extras:
-        also = {}
-        # ---------------------------------------------------------------- BASELINE configs[2]: dual-scale (128 + 416) late fusion
-        # the virtual map of the B 416-px tiles (16 columns, stride 316) scanned at the 128-px scale as well (stride 98): both forwards,
-        # both per-tile paths, cross_scale_consensus_filter and the final merge inside every step (Detect_OBB.py:277-291)
-        cols, rows_ = 16, (B + 15) // 16
-        Wm, Hm = (cols - 1) * 316 + 416, (rows_ - 1) * 316 + 416
-        c128, r128 = len(range(0, Wm - 127, 98)), len(range(0, Hm - 127, 98))  # full 128-px tiles only
-        n128 = c128 * r128
-        rects128 = np.zeros((n128, 4), np.int32)
-        for t in range(n128):
-            x, y = (t % c128) * 98, (t // c128) * 98
-            rects128[t] = (x, y, x + 128, y + 128)
-        m128 = YOLO(weights(3, 1), imgsz=128, precision=args.precision)
-        m416 = YOLO(weights(3, 0), imgsz=416, precision=args.precision)
-        sc = [Scale(m128, 128, n128, 7, rects128, torch.arange(n128, dtype=torch.int32, device=dev)),
-              Scale(m416, 416, B, 0, synthetic_rects(B), torch.arange(B, dtype=torch.int32, device=dev))]
         stepsd = max(3, args.steps // 2)
-        r = measure(sc, stepsd, 2, args.pipeline)
-        flopd = n128 * FLOP_PER_TILE_128 + B * FLOP_PER_TILE
-        also["dual_scale"] = {"workload": "BASELINE configs[2]: dual-scale (128 + 416) 3ch late fusion: per step %d 128-px tiles + %d 416-px tiles of one %dx%d virtual map -> "
-                                          "both forwards + decode + NMS + per-tile merges + cross_scale_consensus_filter + final merge" % (n128, B, Wm, Hm),
-                              "value": B * stepsd / r["dt"], "unit": "416px-tile map areas/s (each with its %.1f 128-px tiles)" % (n128 / B), "dtype": args.precision,
-                              "tiles_per_s_both_scales": (B + n128) * stepsd / r["dt"], "steps": stepsd, "ms_per_step": r["dt"] / stepsd * 1e3,
-                              "forward_ms": {"128": r["fwd_ms"][0], "416": r["fwd_ms"][1]},
-                              "roofline": roofline(args.precision, flopd, r["fwd_ms"][0] + r["fwd_ms"][1]),
-                              "survivor_records_per_step": r["nrec"], "final_detections": r["nmerged"]}
-        del sc
-        m128.close()
-        m416.close()
+        also = {"dual_scale": run_dual(args.precision, stepsd)}
         if args.channels == 3:
-            # ------------------------------------------------------------ BASELINE configs[3] per GPU: 4-channel (RGB + DT-edge) input
-            m4, s4 = single_scale(args.precision, 4)
-            r = measure(s4, stepsd, 2, args.pipeline)
-            also["ch4"] = {"workload": "BASELINE configs[3] per GPU: build_multich (DT-edge channel) + 4-channel forward + the same post-processing",
-                           "value": B * stepsd / r["dt"], "unit": "tiles/s", "dtype": args.precision, "steps": stepsd, "ms_per_step": r["dt"] / stepsd * 1e3,
-                           "roofline": roofline(args.precision, B * FLOP_PER_TILE_4CH, r["fwd_ms"][0])}
-            del s4
-            m4.close()
+            also["ch4"] = run_ch4(args.precision, stepsd)
+        if args.precision == "f32":
+            # ------------------------------------------------------------ the opt-in 16-bit fast mode on the same workloads (never the headline)
+            h16, rf16 = run_single("f16", args.channels, args.steps, 2)
+            f16 = {"value": B * args.steps / h16["dt"], "unit": "tiles/s", "dtype": "f16", "steps": args.steps, "warmup": 2, "ms_per_step": h16["dt"] / args.steps * 1e3,
+                   "roofline": rf16, "survivor_records_per_step": h16["nrec"], "final_detections": h16["nmerged"],
+                   "note": "fp16 storage / fp32 accumulate (YOLO(..., precision='f16')): detections agree with the fp32 pipeline within the tolerances of "
+                           "tests/test_gpu_fp32.py, not bit for bit",
+                   "dual_scale": run_dual("f16", stepsd)}
+            if args.channels == 3:
+                f16["ch4"] = run_ch4("f16", stepsd)
+            also["f16"] = f16
         if rank == 0:
             out["also"] = also
 

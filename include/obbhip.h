@@ -121,6 +121,32 @@ int obb_tile_grid(int32_t H, int32_t W, int32_t tile, int32_t overlap, int32_t *
 int obb_tile_postprocess(obb_ctx *ctx, const float *local_pts, const int32_t *cls, const int32_t *det_tile, int64_t n,
                          const int32_t *rects, int32_t ntiles, int32_t margin, int32_t strike_cls, double *gboxes,
                          double *angle, uint8_t *inside, obb_stream_t s);
+/* The whole stretch between the NMS output and the exchange records of a batch of tiles, on the device with no host-visible count in
+ * between (Detect_OBB.py:228-264 per tile): Results.obb construction of each NMS row (regularize_rboxes, scale_boxes with the tile's
+ * letterbox lb[t] = (gain, pad_x, pad_y) or NULL, xywhr2xyxyxyxy), the per-detection body (:229-262: global corners, border filter with
+ * `margin`), the per-tile merge_detections (:264, threshold iou_thr) and the compaction of the survivors into 48-byte records
+ * {tile id, class, conf (float32 bits), 0, 8 x local corner (float32 bits)} in tile order, merge (confidence) order inside a tile.
+ * det float[B*max_det*7] + count int32[B]: the outputs of obb_decode_nms; tile_ids int32[B]: index of each tile into rects int32[*][4];
+ * records int32[B*max_det*12] (capacity), tile_off int32[B+1] (first record of every tile), *n_records (device) = tile_off[B].
+ * max_det <= 512.  Bit-identical to obb_results -> obb_tile_postprocess -> obb_merge_segments on the same rows (shared device code). */
+int obb_tile_survivors(obb_ctx *ctx, const float *det, const int32_t *count, int32_t B, int32_t max_det, const float *lb,
+                       const int32_t *tile_ids, const int32_t *rects, int32_t margin, int32_t strike_cls, double iou_thr,
+                       int32_t *records, int32_t *tile_off, int32_t *n_records, obb_stream_t s);
+/* Ordered compaction of a merge result (the list comprehension that closes merge_detections, Detect_OBB.py:198-200): out row r =
+ * input row order[i] of the r-th sorted position i with keep[i] != 0; *n_out (device) = number of rows written.  angle / out_angle
+ * may be NULL.  Output buffers hold n rows. */
+int obb_select_kept(obb_ctx *ctx, const int32_t *order, const uint8_t *keep, int64_t n, const double *boxes, const int32_t *cls,
+                    const double *conf, const double *angle, double *out_boxes, int32_t *out_cls, double *out_conf, double *out_angle,
+                    int32_t *n_out, obb_stream_t s);
+/* Consumer side of the 48-byte records: global float64 corners (float32 local corner + integer tile offset: exact), class, confidence
+ * widened to float64 and the strike angle (Detect_OBB.py:229-234, 251-254), straight from the packed rows records int32[n][12]. */
+int obb_records_to_dets(obb_ctx *ctx, const int32_t *records, int64_t n, const int32_t *rects, int32_t strike_cls, double *gboxes,
+                        int32_t *cls, double *conf, double *angle, obb_stream_t s);
+/* Multi-GPU exchange: the valid rows of a fixed-capacity all-gather buffer recv int32[world][capacity+1][12]
+ * (row 0 of every rank's block carries its record count in column 0) -> dense out int32[<= world*capacity][12] in rank order;
+ * counts int32[world+1] (device): every rank's count as sent (a count above `capacity` tells the caller to repeat the exchange with a
+ * larger one) and, last, the number of rows written. */
+int obb_gather_compact(obb_ctx *ctx, const int32_t *recv, int32_t world, int32_t capacity, int32_t *out, int32_t *counts, obb_stream_t s);
 /* Gather all full-size tiles of one image into an NHWC uint8 batch (Detect_OBB.py:218-220 crop, vectorised).
  * image uint8[H*W*C]; rects device int32[ntiles*4] must all be tile x tile. */
 int obb_gather_tiles(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, const int32_t *rects,
@@ -130,6 +156,17 @@ int obb_gather_tiles(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, i
  * call site Detect_OBB.py:81-83).  Returns gain and left/top pad through *_host pointers. */
 int obb_letterbox(obb_ctx *ctx, const uint8_t *image, int32_t H, int32_t W, int32_t C, int32_t x, int32_t y, int32_t x2,
                   int32_t y2, int32_t imgsz, uint8_t *out, int32_t out_h, int32_t out_w, obb_stream_t s);
+
+/* ------------------------------------------------------------------ training step, slice 2 */
+/* RotatedTaskAlignedAssigner.forward of ultralytics==8.3.196 (utils/tal.py; reached from `model.train(...)`, Train_OBB.py:796-841, through
+ * v8OBBLoss with topk = 10, alpha = 0.5, beta = 6.0): pd_scores float[bs][na][nc] (sigmoid scores), pd_bboxes float[bs][na][5] (x, y, w,
+ * h, theta in pixels), anc_points float[na][2], gt_labels int32[bs][n_max], gt_bboxes float[bs][n_max][5], mask_gt uint8[bs][n_max] ->
+ * target_labels int32[bs][na], target_bboxes float[bs][na][5], target_scores float[bs][na][nc], fg_mask uint8[bs][na],
+ * target_gt_idx int32[bs][na].  na <= 10240.  All device pointers. */
+int obb_rotated_tal_assign(obb_ctx *ctx, const float *pd_scores, const float *pd_bboxes, const float *anc_points, const int32_t *gt_labels,
+                           const float *gt_bboxes, const uint8_t *mask_gt, int32_t bs, int32_t na, int32_t nc, int32_t n_max, int32_t topk,
+                           float alpha, float beta, int32_t *target_labels, float *target_bboxes, float *target_scores, uint8_t *fg_mask,
+                           int32_t *target_gt_idx, obb_stream_t s);
 
 /* ------------------------------------------------------------------ S1: model(...) -> results[0].obb  (Detect_OBB.py:26,81-83,228-231) */
 /* Weight blob ("OBBW" format, produced by the Python side from BN-folded conv weights) for a

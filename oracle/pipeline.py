@@ -14,13 +14,14 @@ STRIKE = 1
 class OracleModel:
     """model(crop_bgr_uint8, conf=...) -> [obj] with obj.obb rows, Ultralytics-shaped (Detect_OBB.py:81-83, 228-231)."""
 
-    def __init__(self, net, imgsz=416, precision="fp32", head_fn=None, iou=0.7, max_det=300):
+    def __init__(self, net, imgsz=416, precision="fp32", head_fn=None, iou=0.7, max_det=300, multich_fn=None):
         self.net, self.imgsz, self.precision, self.head_fn, self.iou, self.max_det = net, imgsz, precision, head_fn, iou, max_det
+        self.multich_fn = multich_fn  # tests: the 4-channel input builder under test instead of the numpy restatement (isolates the forward)
 
     def predict_rows(self, crop, conf):
         if self.net.ch == 4 and crop.shape[2] == 3:  # run_inference_on_crop :76-77: net_input = build_multich(crop_bgr, channels)
             from . import dtedge
-            crop = dtedge.build_multich(crop, 4)
+            crop = self.multich_fn(crop) if self.multich_fn is not None else dtedge.build_multich(crop, 4)
         lb, p = pp.letterbox(crop, self.imgsz)
         h, w = lb.shape[:2]
         head = self.head_fn(lb[None]) if self.head_fn is not None else self.net.forward_raw(lb[None], self.precision)

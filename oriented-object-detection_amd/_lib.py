@@ -4,7 +4,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("OBB_LIB") or os.path.join(_HERE, "libobbhip.so")  # OBB_LIB: diagnostic builds of the same library (tools/stamp_conv.sh)
+SO_PATH = os.path.join(_HERE, "libobbhip.so")
+if os.environ.get("OBB_LIB"):  # diagnostic builds of the same library (tools/stamp_conv.sh): never silently
+    import sys
+    SO_PATH = os.environ["OBB_LIB"]
+    sys.stderr.write("oriented_object_detection_amd: OBB_LIB is set -- loading the DIAGNOSTIC library %s instead of the product build\n" % SO_PATH)
 _lib = None
 
 c_dp, c_fp, c_ip, c_lp, c_bp = (C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32),
@@ -30,6 +34,11 @@ SIGNATURES = {
     "obb_consensus": [_V, _V, _V, _V, c_lp, C.c_int32, C.c_double, C.c_double, C.c_double, _V, _V, _V],
     "obb_tile_grid": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_ip, C.c_int64, c_lp],
     "obb_tile_postprocess": [_V, _V, _V, _V, C.c_int64, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V],
+    "obb_tile_survivors": [_V, _V, _V, C.c_int32, C.c_int32, _V, _V, _V, C.c_int32, C.c_int32, C.c_double, _V, _V, _V, _V],
+    "obb_select_kept": [_V, _V, _V, C.c_int64, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V],
+    "obb_records_to_dets": [_V, _V, C.c_int64, _V, C.c_int32, _V, _V, _V, _V, _V],
+    "obb_gather_compact": [_V, _V, C.c_int32, C.c_int32, _V, _V, _V],
+    "obb_rotated_tal_assign": [_V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _V, _V, _V, _V, _V, _V],
     "obb_gather_tiles": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, C.c_int32, C.c_int32, _V, _V],
     "obb_letterbox": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V,
                       C.c_int32, C.c_int32, _V],

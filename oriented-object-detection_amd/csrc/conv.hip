@@ -1159,8 +1159,12 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2(L.CK / 8);
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
+#if defined(OBB_STAMPS) || defined(OBB_DIAG)  // timing-only ablations exist in the diagnostic build alone (tools/stamp_conv.sh): the product library ignores the variable
     static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
     P.dbg = dbg;
+#else
+    P.dbg = 0;
+#endif
     P.stamps = nullptr;
 #ifdef OBB_STAMPS
     static unsigned long long *stamp_dev = nullptr;

@@ -12,12 +12,11 @@
 #include <cstdlib>
 
 #include "ctx.h"
+#include "post_device.h"
 
 namespace obb {
 
 static constexpr int kRegMaxD = 16;
-static constexpr float kPiF = 3.14159274101257324f;      // (float)math.pi
-static constexpr float kHalfPiF = 1.57079637050628662f;  // (float)(math.pi / 2)
 static constexpr float kMaxWh = 7680.0f;
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -593,35 +592,14 @@ __global__ __launch_bounds__(256) void k_probiou_nms_list(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------- results
-__device__ __forceinline__ float py_remainder(float a, float b) {  // torch.remainder / Python % for b > 0
-    float r = fmodf(a, b);
-    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
-    return r;
-}
-
 __global__ __launch_bounds__(256) void k_results(const float *__restrict__ det, const float *__restrict__ lb, int64_t n,
                                                 float *__restrict__ xywhr, float *__restrict__ pts) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float *d = det + i * 7;
-    float x = d[0], y = d[1], w = d[2], h = d[3], t = d[6];
-    bool swap = py_remainder(t, kPiF) >= kHalfPiF;  // regularize_rboxes
-    float w_ = swap ? h : w, h_ = swap ? w : h;
-    t = py_remainder(t, kHalfPiF);
-    if (lb) {  // scale_boxes(xywh=True): subtract the letterbox pad, divide by the gain
-        float gain = lb[i * 3], px = lb[i * 3 + 1], py = lb[i * 3 + 2];
-        x -= px; y -= py;
-        x /= gain; y /= gain; w_ /= gain; h_ /= gain;
-    }
-    xywhr[i * 5] = x; xywhr[i * 5 + 1] = y; xywhr[i * 5 + 2] = w_; xywhr[i * 5 + 3] = h_; xywhr[i * 5 + 4] = t;
-    float c = cosf(t), s = sinf(t);  // xywhr2xyxyxyxy
-    float v1x = w_ / 2.0f * c, v1y = w_ / 2.0f * s;
-    float v2x = -h_ / 2.0f * s, v2y = h_ / 2.0f * c;
-    float *p = pts + i * 8;
-    p[0] = x + v1x + v2x; p[1] = y + v1y + v2y;
-    p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
-    p[4] = x - v1x - v2x; p[5] = y - v1y - v2y;
-    p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
+    float r5[5], p[8];
+    results_row(det + i * 7, lb ? lb + i * 3 : nullptr, r5, p);  // post_device.h
+    for (int k = 0; k < 5; ++k) xywhr[i * 5 + k] = r5[k];
+    for (int k = 0; k < 8; ++k) pts[i * 8 + k] = p[k];
 }
 
 // ---------------------------------------------------------------------------------------------- tiler crops / letterbox

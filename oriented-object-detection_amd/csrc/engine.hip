@@ -46,7 +46,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
+enum OpType { OP_CONV32, OP_STEM32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
 
 struct Op {
     OpType type;
@@ -56,6 +56,7 @@ struct Op {
     int Ho = 0, Wo = 0;      // output spatial dims
     ConvLaunch conv;         // OP_CONV
     Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
+    Stem32Launch stem32;     // OP_STEM32 (fp32 mode: network input layer as row stripes)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     FrontLaunch front;       // OP_FRONT (model.0 + model.1 + model.2.cv1 in one launch)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
@@ -236,6 +237,7 @@ struct Builder {
         if (!r || !r2 || err) return false;
         if (r->g != 1 || r2->g != 1 || r2->k != 1 || r2->s != 1 || r2->act || r2->c1 != r->c2 || r->s != 1) return false;
         int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
+        if (M.f32) return conv32_tail_supported(plan_conv32(r->k, r->s, r->c1, r->c2, Ho, Wo, false), r->c2, r2->c2);
         ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo, M.o.pair);
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2);
     }
@@ -248,6 +250,7 @@ struct Builder {
         if (!r || !r2 || err) return false;
         if (r->g != 1 || r2->g != 1 || r->k != 3 || r2->k != 1 || r2->s != 1 || !r2->act || !r->act || r2->c1 != r->c2) return false;
         int Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1, Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
+        if (M.f32) return conv32_tail_supported(plan_conv32(r->k, r->s, r->c1, r->c2, Ho, Wo, false), r->c2, r2->c2);
         ConvTiling t = plan_conv(r->k, r->s, r->c1, r->c2, Ho, Wo, M.o.pair);
         return conv_tail_supported(r->k, t.MF, t.NF, r->c2, r2->c2, true, t.TH);
     }
@@ -311,21 +314,56 @@ struct Builder {
         op.Ho = (Hin + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.Wo = (Win + 2 * (r->k / 2) - r->k) / r->s + 1;
         op.one_d = (r->k == 1);
-        if (M.f32) {  // fp32-arithmetic mode: one exact-f32 MFMA kernel per layer
-            if (op.vin || tail_name) { err = set_error(ctx, OBB_ERR_STATE, "layer %s: fused forms do not exist in fp32 mode", name.c_str()); return; }
+        if (M.f32 && in_u8 && M.o.stem && !perm && !tail_name && head_level < 0 && !res.C && stem32_supported(cin, r->c2, r->k, r->s, Hin, Win)) {
+            op.type = OP_STEM32;
+            Stem32Launch &S = op.stem32;
+            S.Hin = Hin; S.Win = Win; S.cin = cin; S.cout = r->c2; S.act = r->act;
+            S.wpk = upload(pack_stem32_weights(r->w, r->c2, cin, M.ch == 3));
+            std::vector<float> sb(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r->c2; ++c) sb[c] = r->b[c];
+            S.bias = upload(sb);
+            S.lut = M.lut32_dev;
+            op.macs = (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+            P.macs_per_img += op.macs;
+            P.ops.push_back(op);
+            P.named[name] = out;
+            return;
+        }
+        if (M.f32) {  // fp32-arithmetic mode: exact-f32 MFMA kernels (f32path.hip)
             op.type = OP_CONV32;
             Conv32Launch &L = op.c32;
-            const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8);
+            const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8, op.vin);
             L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act; L.in_u8 = in_u8; L.flip_bgr = (in_u8 && M.ch == 3);
-            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC;
+            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM;
             L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
             L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
+            if (op.vin && (P.bufs[in.buf].va_C % t.CK || t.WC != 4)) { err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the virtual concat in fp32 mode", name.c_str()); return; }
             L.wpk = upload(pack_conv32_weights(r->w, r->c2, cin, r->k, t, perm, in_u8));
             std::vector<float> bias32(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
             for (int c = 0; c < r->c2; ++c) bias32[c] = r->b[perm ? perm[c] : c];
             L.bias = upload(bias32);
             L.lut = M.lut32_dev;
             op.macs = (double)op.Ho * op.Wo * r->c2 * cin * r->k * r->k;
+            if (tail_name) {  // fused trailing 1x1: `out` is the slice the TAIL writes (head rows, or the cv1 output of a C3k2 block)
+                const ConvRecord *r2 = rec(tail_name);
+                if (!r2 || err) return;
+                if (!conv32_tail_supported(t, r->c2, r2->c2) || (r2->act && (r2->c2 != out.C || head_level >= 0))) {
+                    err = set_error(ctx, OBB_ERR_STATE, "fused 1x1 %s: no fp32 kernel for this pair", tail_name);
+                    return;
+                }
+                const Conv32Tiling t2{1, 1, r->c2, 1, 1};
+                L.tail_w = upload(pack_conv32_weights(r2->w, r2->c2, r->c2, 1, t2, nullptr, false));
+                std::vector<float> b2(((size_t)r2->c2 + 63) / 64 * 64 + 64, 0.f);
+                for (int c = 0; c < r2->c2; ++c) b2[c] = r2->b[c];
+                L.tail_b = upload(b2);
+                L.tail_cout = r2->c2; L.tail_act = r2->act;
+                op.name = name + "+" + tail_name;
+                op.macs += (double)op.Ho * op.Wo * r2->c2 * r->c2;
+                P.macs_per_img += op.macs;
+                P.ops.push_back(op);
+                if (r2->act) P.named[tail_name] = out;
+                return;
+            }
             P.macs_per_img += op.macs;
             P.ops.push_back(op);
             P.named[name] = out;
@@ -418,7 +456,7 @@ struct Builder {
     // DWConv 3x3 `dwname` -> Conv 1x1 `pwname` [-> plain 1x1 `tailname` into the head tensor] as one stripe kernel (dwpw.hip).
     // Returns false (nothing emitted) if the shapes have no kernel.
     bool dwpw(const std::string &dwname, const std::string &pwname, Slice in, int H, int W, Slice out, const char *tailname = nullptr, int head_level = -1) {
-        const bool on = M.tail && M.o.dwpw;
+        const bool on = M.tail && M.o.dwpw && !M.f32;
         const ConvRecord *rd = rec(dwname), *rp = rec(pwname), *rt = tailname ? rec(tailname) : nullptr;
         if (!on || !rd || !rp || (tailname && !rt) || err) return false;
         if (in.buf < 0 || P.bufs[in.buf].blk || P.bufs[in.buf].virt || rd->g != rd->c1 || rd->c1 != rd->c2 || rd->k != 3 || rd->s != 1 || rd->c1 != in.C || !rd->act ||
@@ -546,7 +584,7 @@ struct Builder {
 
     void c3k(const std::string &name, Slice in, int H, int W, Slice out, int n) {
         int c_ = out.C / 2;
-        const bool img_on = M.hmerge && M.o.c3kimg;
+        const bool img_on = M.hmerge && M.o.c3kimg && !M.f32;
         if (img_on && in.buf >= 0 && out.buf >= 0 && !P.bufs[in.buf].blk && !P.bufs[in.buf].virt && !P.bufs[out.buf].blk &&
             c3kimg_supported(H, W, in.C, c_, out.C, n)) {
             // the whole block in one launch: weight stream = the six layers' MFMA fragments back to back
@@ -692,7 +730,7 @@ struct Builder {
         int c_ = c1024 / 2;
         int cat9 = buf(H32, W32, 4 * c_, "cat9");
         conv("model.9.cv1", whole(b8), H32, W32, sub(cat9, 0, c_));
-        if (M.o.sppf_fuse && !M.f32 && c_ % 32 == 0 && (size_t)H32 * W32 * 128 <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
+        if (M.o.sppf_fuse && c_ % 32 == 0 && (size_t)H32 * W32 * (M.f32 ? 256 : 128) <= 64 * 1024) {  // the three pools in one launch, planes resident in LDS
             Op op; op.type = OP_SPPF; op.name = "sppf.pools"; op.in = sub(cat9, 0, c_); op.out = whole(cat9); op.H = H32; op.W = W32; op.Ho = H32; op.Wo = W32;
             P.ops.push_back(op);
         } else {
@@ -764,7 +802,8 @@ struct Builder {
             //  -- except where k_conv3_pair takes the merged 64 + 16 couts as ONE group of five fragments (64 input channels, 13 x 13 tiles):
             //  no padded block there, and the feature map is read once instead of twice)
             const bool pair80 = M.o.pair && !M.f32 && P.bufs[feats[i]].C == 64 && c2 == 64 && c4 == 16 && Hs[i] % 13 == 0 && Ws[i] % 13 == 0;
-            const std::string mn = (c2 % 16 == 0 && c4 % 16 == 0 && (Hs[i] * Ws[i] <= 256 || pair80)) ? merged_record(p + ".0", p4 + ".0") : std::string();
+            // (fp32 mode: never -- the exact-f32 MFMA is the bound there and the merged 80 couts would pad to two 64-cout blocks)
+            const std::string mn = (!M.f32 && c2 % 16 == 0 && c4 % 16 == 0 && (Hs[i] * Ws[i] <= 256 || pair80)) ? merged_record(p + ".0", p4 + ".0") : std::string();
             if (err) return err;
             int t1, t2 = buf(Hs[i], Ws[i], c2, p + ".t2");
             if (!mn.empty()) {  // box and angle branch start with a 3x3 conv on the same feature map: one launch, [t1 | u1] in 16-channel blocks
@@ -913,12 +952,21 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 L.B = B;
                 if (op.in.buf == -1) {
                     L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
+                } else if (op.vin) {
+                    const Buf &vb = P.bufs[op.in.buf];
+                    L.in = tref(P, Slice{vb.va_buf, vb.va_co, vb.va_C}, boff);
+                    L.in2 = tref(P, Slice{vb.vb_buf, vb.vb_co, vb.vb_C}, boff);
+                    L.up_c = vb.va_C; L.up_W = op.W; L.up_HW = op.H * op.W;
                 } else L.in = tref(P, op.in, boff);
+                TensorRef o;
+                int o_hw = 0;
                 if (op.head_level >= 0) {
-                    L.out.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
-                    L.out.bs = (int64_t)P.A * P.no_pad; L.out.cs = P.no_pad; L.out.co = op.out.co;
-                    if (op.one_d) L.out_hw = op.Ho * op.Wo;
-                } else L.out = tref(P, op.out, boff);
+                    o.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
+                    o.bs = (int64_t)P.A * P.no_pad; o.cs = P.no_pad; o.co = op.out.co;
+                    if (op.one_d) o_hw = op.Ho * op.Wo;
+                } else o = tref(P, op.out, boff);
+                if (L.tail_cout > 0) { L.tail_out = o; L.tail_out_hw = o_hw; }
+                else { L.out = o; L.out_hw = o_hw; }
                 L.res = tref(P, op.res, boff);
                 if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
                     const int64_t npx = (int64_t)B * op.Ho * op.Wo;
@@ -926,6 +974,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     L.tiles_y = 1; L.tiles_x = (int)((npx + L.TW - 1) / L.TW);
                 }
                 e = launch_conv32(L, st);
+                break;
+            }
+            case OP_STEM32: {
+                Stem32Launch L = op.stem32;
+                L.B = B; L.in = tiles; L.out = tref(P, op.out, boff);
+                e = launch_stem32(L, st);
                 break;
             }
             case OP_CONV: {
@@ -991,7 +1045,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_bneck(L, st);
                 break;
             }
-            case OP_SPPF: e = launch_sppf_pools(tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
+            case OP_SPPF:
+                if (M.f32) { e = launch_sppf_pools_f32(tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break; }
+                e = launch_sppf_pools(tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
             case OP_POOL:
                 if (M.f32) { e = launch_maxpool5_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, st); break; }
                 e = launch_maxpool5(tref(P, op.in, boff), tref(P, op.out, boff), B, op.H, op.W, op.in.C, M.f16, st); break;
@@ -1011,7 +1067,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 break;
             }
             case OP_ATTN:
-                if (M.f32) { e = launch_attention_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, st); break; }
+                if (M.f32) { e = launch_attention_f32(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.o.attn_mfma, st); break; }
                 e = launch_attention(tref(P, op.in, boff), tref(P, op.out, boff), B, op.N, op.nh, op.kd, op.hd, M.f16, M.o.attn_mfma, st); break;
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
@@ -1087,7 +1143,6 @@ int obb_model_load(obb_ctx *ctx, const void *blob_host, size_t bytes) {
     M->o = ctx->opt;
     M->tail = ctx->opt.tail;
     M->upfold = ctx->opt.upfold;
-    if (M->f32) { M->tail = false; M->upfold = false; }  // fp32 arithmetic: one kernel per layer, fp32 NHWC buffers
     M->hmerge = M->tail && ctx->opt.hmerge;
     M->bneck = M->tail && ctx->opt.bneck;  // both swallow intermediate activations ("tail" = 0 keeps every layer observable)
     if (M->f32) {  // `im.float() / 255`: IEEE division, one table entry per byte value
@@ -1237,8 +1292,8 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
         switch (op.type) {
             case OP_CONV32: {
                 const Conv32Launch &L = op.c32;
-                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d CK%d WC%d lds%d macs%.0f\n", op.name.c_str(), L.ks, L.stride, L.cin,
-                         L.cout, op.Ho, op.Wo, L.TH, L.TW, L.CK, L.WC, (int)conv32_lds_bytes(L), op.macs);
+                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d CK%d WC%d MFM%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
+                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.CK, L.WC, L.MFM, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
                 break;
             }
             case OP_CONV: {
@@ -1261,6 +1316,9 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_STEM32:
+                snprintf(line, sizeof line, "stem32 %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem32.cin, op.stem32.cout, op.Ho, op.Wo, 4, op.macs);
+                break;
             case OP_STEM:
                 snprintf(line, sizeof line, "stem %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem.cin, op.stem.cout, op.Ho, op.Wo, 4, op.macs);
                 break;

@@ -1,7 +1,8 @@
 // fp32-arithmetic form of the OBBModel forward (obb_set_option "precision" = 32): what the reference computes with Ultralytics'
 // default half=False (Detect_OBB.py:79-83).  Activations and weights stay fp32 end to end; the convolutions run on the exact-f32
-// matrix instruction v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered fmaf chain), everything else on the fp32 VALU.  One kernel per
-// layer (no fusion): every activation is observable, which is what the tight parity tests want.  See f32path.hip.
+// matrix instruction v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered fmaf chain), everything else on the fp32 VALU.  Fused forms (a
+// trailing 1x1 behind its producer, Upsample + Concat read in place, merged sibling convs) keep the engine's switches: with "tail" = 0
+// the plan is one kernel per layer and every activation is observable, which is what the tight parity tests want.  See f32path.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,13 +23,27 @@ struct Conv32Launch {
     int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0;
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 1, in_u8 = 0, flip_bgr = 0;
     int out_hw = 0;  // > 0: 1-D launch (B = 1, H = 1, W = batch * pixels) whose output rows are split per image: P -> (P / out_hw, P % out_hw)
-    // tiling (plan_conv32): output tile TH x TW (<= 208 pixels = 13 fragments of 16), CK input channels per LDS stage, WC waves along cout
-    int TH = 1, TW = 208, CK = 16, WC = 4;
+    // 1x1 over a virtual concat (up_c > 0): input channels [0, up_c) = nearest-x2 upsample of `in` (a tensor of half the resolution),
+    // channels [up_c, cin) = `in2` (full resolution); neither the upsampled tensor nor the concat exists.  1-D launches only.
+    TensorRef in2;
+    int up_c = 0, up_W = 0, up_HW = 0;  // full-resolution width and pixels per image
+    // optional fused trailing 1x1 conv (tail_cout > 0): consumes THIS layer's activated output tile straight from LDS (this layer's
+    // own output is then never written); tail_act = SiLU on the tail; its rows go to tail_out (an activation slice or the head tensor)
+    const float *tail_w = nullptr;  // pack_conv32_weights(w2, tail_cout, cout, 1, {1, *, CK = cout, *})
+    const float *tail_b = nullptr;  // padded like `bias`
+    int tail_cout = 0, tail_act = 0;
+    TensorRef tail_out;
+    int tail_out_hw = 0;
+    // tiling (plan_conv32): output tile TH x TW (<= 16 * (8 / WC) * MFM pixels), CK input channels per LDS stage, WC of the workgroup's 8
+    // waves along cout (16 couts each), the other 8 / WC along the pixel fragments, MFM fragments of 16 pixels per wave
+    int TH = 1, TW = 208, CK = 16, WC = 4, MFM = 7;
     int tiles_y = 1, tiles_x = 1;
 };
 
-struct Conv32Tiling { int TH, TW, CK, WC; };
-Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8);
+struct Conv32Tiling { int TH, TW, CK, WC, MFM; };
+Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat = false);  // vcat: the input is a virtual [upsample | skip] concat
+// true if the 1x1 conv (cout1 -> cout2) can run as the fused tail of a layer tiled as `t`
+bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2);
 // fp32 OIHW -> A-operand order [cout fragment of 16][stage][k16 step][lane][4]: lane (r = lane & 15, g = lane >> 4) holds the weights of
 // cout r for the four k values of its 4-channel chunk q = 4 * step + g (tap = q / (CK/4), channels 4 * (q % (CK/4)) ..+3); element s of
 // the vector feeds MFMA step s.  cout_perm (optional): logical cout -> source row.
@@ -36,10 +51,23 @@ std::vector<float> pack_conv32_weights(const float *w_oihw, int cout, int cin, i
 size_t conv32_lds_bytes(const Conv32Launch &L);
 hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st);
 
+// model.0 (3x3 s2 on the uint8 tile) as full-width row stripes: see k_stem_f32
+struct Stem32Launch {
+    const uint8_t *in = nullptr;  // [B][Hin][Win][cin] bytes
+    TensorRef out;                // fp32 NHWC slice, Hin/2 x Win/2 x cout
+    const float *wpk = nullptr;   // pack_stem32_weights
+    const float *bias = nullptr, *lut = nullptr;
+    int B = 0, Hin = 0, Win = 0, cin = 3, cout = 16, act = 1;
+};
+bool stem32_supported(int cin, int cout, int ks, int stride, int Hin, int Win);
+std::vector<float> pack_stem32_weights(const float *w_oihw, int cout, int cin, bool flip_bgr);
+hipError_t launch_stem32(const Stem32Launch &L, hipStream_t st);
+
 hipError_t launch_dwconv3_f32(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w9c, const float *bias, int B, int H, int W,
                               int C, int act, hipStream_t st);
 hipError_t launch_maxpool5_f32(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st);
 hipError_t launch_upsample2_f32(const TensorRef &in, const TensorRef &out, int B, int H, int W, int C, hipStream_t st);
-hipError_t launch_attention_f32(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, hipStream_t st);
+hipError_t launch_sppf_pools_f32(const TensorRef &cat, int B, int H, int W, int C, hipStream_t st);  // cat = [x | m1 | m2 | m3], C channels each
+hipError_t launch_attention_f32(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool use_mfma, hipStream_t st);
 
 }  // namespace obb

@@ -16,12 +16,13 @@
 //   * measured and dropped: prefetching the next channel stage into registers under the MFMAs (176 VGPRs -> two waves per SIMD
 //     instead of three: 40.1 -> 42.1 ms per 1024 tiles), and dword loads of 4-pixel groups + an LDS table for the uint8 input layer
 //     (596 -> 771 us per 256 tiles).
-//   * epilogue: + bias, SiLU (expf + IEEE division, like torch), + residual, fp32 store into a channel slice of the consumer's buffer.
+//   * epilogue: + bias, SiLU (v_exp_f32 + v_rcp_f32, 1 ulp each: silu32 below), + residual, fp32 store into a channel slice of the consumer's buffer.
 #include "f32path.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace obb {
 
@@ -30,9 +31,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct C32Params {
     const void *in; int64_t in_bs; int in_cs, in_co;
+    const void *in2; int in2_cs, in2_co; unsigned in2_span_bytes; int up_c, up_W, up_HW;  // VCAT: second source of a virtual [upsample | skip] concat
     float *out; int64_t out_bs; int out_cs, out_co;
     const float *res; int64_t res_bs; int res_cs, res_co;
     const float *wpk, *bias, *lut;
+    const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
     float inv_twin, inv_tw;
@@ -43,10 +46,22 @@ struct C32Params {
 // summation-order noise of an fp32 convolution (~sqrt(K) * 6e-8); the library expf + IEEE division cost 4x the epilogue time
 __device__ __forceinline__ float silu32(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-template <int KS, int MFM, int WC, bool IN_U8>
-__global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
+// Workgroup = NW waves: WC of them along cout (16 couts each), WP = NW / WC along the pixel fragments; wave (wc, wp) owns the fragments
+// f = wp + WP * i, i < MFM, of the tile (interleaved, so that a partly filled tile leaves every wave about the same work).
+//   * BOTH operands of a channel stage live in LDS: the activation tile [pixels + halo][CK] and the stage's weights of the workgroup's WC
+//     cout fragments (kst pieces of 1 KiB each, already in A-fragment order).  The k loop therefore contains no global load at all
+//     (a per-wave weight stream from L2 cost a `s_waitcnt vmcnt(0)` per k step -- the register rotation reads the youngest load -- and
+//     with it every overlap of the next stage's fetch), only ds_read_b128 + MFMA.
+//   * pipeline per channel stage (one register set, one LDS buffer): the NEXT stage's activation chunks and weight pieces are fetched
+//     into registers while this stage's k loop runs; barrier; LDS write; barrier; issue the fetch after next; k loop.
+//   * TAIL (= WC2 > 0): the activated output tile goes to LDS instead of memory and a second GEMM (K = cout, 16 * WC2 >= cout2 couts)
+//     runs from there: the producer's tensor is never written.  Used for the last 1x1 of every head branch and for the cv1 of a
+//     C3k2 block behind its stride-2 conv.
+//   * VCAT: the 1x1 behind [Upsample | skip] reads both sources in place (stage-uniform choice: up_c is a multiple of CK).
+template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P) {  // <= 128 VGPRs: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PAD = KS / 2;
+    constexpr int NT = NW * 64, WP = NW / WC, PAD = KS / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the fragment guards below become scalar branches
     const int g = lane >> 4, pl = lane & 15;
@@ -65,53 +80,120 @@ __global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
     const int tx_i = t % P.tiles_x, r_ = t / P.tiles_x, ty_i = r_ % P.tiles_y, b = r_ / P.tiles_y;
     const int oy0 = ty_i * P.TH, ox0 = tx_i * P.TW;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    // valid pixels of this tile (edge tiles are clipped): fragments past them are not computed
+    const int vh = min(P.TH, P.Hout - oy0), vw = min(P.TW, P.Wout - ox0);
     const int npix = P.TH * P.TW;
+    const int nfrag = ((vh == P.TH ? npix : vh * P.TW) + 15) >> 4;  // whole rows: a clipped tile loses its trailing rows (1-D: TH = 1, all kept)
+    const int nfrag1 = (P.TH == 1) ? ((vw + 15) >> 4) : nfrag;
+    const bool lastv = wp + WP * (MFM - 1) < nfrag1;  // (wave-uniform) the last fragment of this wave exists
 
     int pixbase[MFM];
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) {
-        const int p = (wp * MFM + mf) * 16 + pl;
+        const int p = (wp + WP * mf) * 16 + pl;
         const int ty = (int)(((float)p + 0.5f) * P.inv_tw);
         const int tx = p - ty * P.TW;
         pixbase[mf] = p < npix ? ((ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
     }
     const int F = cb * WC + wc;  // cout fragment of this wave
-    const float *wbase = P.wpk + (size_t)F * P.nstage * P.kst * 256 + lane * 4;
+    // weights of (cout block cb, stage): WC * kst pieces of 1 KiB, contiguous (pack_conv32_weights); LDS image behind the activation tile
+    const int act_bytes = ((in_px * PST + 1023) >> 10) << 10;
+    const int nwchunk = WC * P.kst * 64;  // 16-B chunks of one stage's weights
+    const float *wblk = P.wpk + (size_t)cb * P.nstage * nwchunk * 4;
+    char *const wlds = smem + act_bytes;
 
     f32x4 acc[MFM];
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging plan: this thread moves the 16-B chunks idx = tid + k * 256 of the [in_px][CK] tile.  Activations come through buffer
+    // staging plan: this thread moves the 16-B chunks idx = tid + k * NT of the [in_px][CK] tile.  Activations come through buffer
     // loads (descriptor in SGPRs, one 32-bit byte offset per chunk): an offset past the descriptor's range reads zeros, which is how
     // the zero padding is written
-    constexpr int MAXLD = IN_U8 ? 5 : (KS == 1 ? 8 : 9);  // plan_conv32 keeps a stage within that many x 256 chunks of 16 B
+    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (VCAT ? 4 : 7) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
+    constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4)
     constexpr unsigned NOPIX = 0xffffffffu;
-    const int nchunk = in_px << P.sh;
-    unsigned goff[IN_U8 ? 1 : MAXLD];
-    __amdgpu_buffer_rsrc_t in_rsrc;
+    const int nchunk = in_px * cpk;
+    unsigned goff[IN_U8 ? 1 : MAXLD], goff2[VCAT ? MAXLD : 1];
+    __amdgpu_buffer_rsrc_t in_rsrc, in2_rsrc;
     if constexpr (!IN_U8) {
         in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in + (int64_t)b * P.in_bs + P.in_co), 0, (int)P.in_span_bytes, 0x00020000);
+        if constexpr (VCAT) in2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in2 + P.in2_co), 0, (int)P.in2_span_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
-            const int idx = tid + k * 256;
-            const int pix = idx >> P.sh, c = idx & (cpk - 1);
+            const int idx = tid + k * NT;
+            int pix, c;
+            if constexpr (KS == 1) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
+            else { pix = idx >> P.sh; c = idx & (cpk - 1); }
             const int iy = (int)(((float)pix + 0.5f) * P.inv_twin), ix = pix - iy * TWin;
             const int gy = iy0 + iy, gx = ix0 + ix;
             const bool ok = idx < nchunk && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
-            goff[k] = ok ? (unsigned)((((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+            if constexpr (VCAT) {  // 1-D: gx = flattened (image, y, x) of the full-resolution level
+                const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
+                const int yy = r / P.up_W, xx = r - yy * P.up_W;
+                const int64_t sp = (int64_t)bb * (P.up_HW >> 2) + (int64_t)(yy >> 1) * (P.up_W >> 1) + (xx >> 1);
+                goff[k] = ok ? (unsigned)((sp * P.in_cs + c * 4) * 4) : NOPIX;
+                goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + c * 4) * 4) : NOPIX;
+            } else {
+                goff[k] = ok ? (unsigned)((((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+            }
         }
     }
 
+    u32x4 pre[IN_U8 ? 1 : MAXLD];
+    f32x4 prew[MAXW];
+    auto fetch = [&](int stage) {  // issue the loads of one channel stage (registers `pre`, `prew`)
+        const float *wsrc = wblk + (size_t)stage * nwchunk * 4;
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) {
+            const int idx = tid + k * NT;
+            prew[k] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)min(idx, nwchunk - 1) * 4);
+        }
+        if constexpr (!IN_U8) {
+            bool second = false;
+            unsigned add = (unsigned)(stage * P.CK * 4);
+            if constexpr (VCAT) {
+                second = stage * P.CK >= P.up_c;
+                if (second) add -= (unsigned)(P.up_c * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < MAXLD; ++k) {
+                if constexpr (VCAT) {
+                    const unsigned o = second ? goff2[k] : goff[k];
+                    pre[k] = __builtin_amdgcn_raw_buffer_load_b128(second ? in2_rsrc : in_rsrc, o == NOPIX ? NOPIX : o + add, 0, 0);
+                } else {
+                    pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[k] == NOPIX ? NOPIX : goff[k] + add, 0, 0);
+                }
+            }
+        }
+    };
+    auto commit = [&]() {  // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < nwchunk) *reinterpret_cast<f32x4 *>(wlds + idx * 16) = prew[k];
+        }
+        if constexpr (!IN_U8) {
+#pragma unroll
+            for (int k = 0; k < MAXLD; ++k) {
+                const int idx = tid + k * NT;
+                int pix, c;
+                if constexpr (KS == 1) { pix = idx / cpk; c = idx - pix * cpk; }
+                else { pix = idx >> P.sh; c = idx & (cpk - 1); }
+                if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + pix * PST + c * 16) = pre[k];
+            }
+        }
+    };
+
+    fetch(0);
+    const char *const wfrag = wlds + wc * P.kst * 1024 + lane * 16;
     for (int stage = 0; stage < P.nstage; ++stage) {
-        __syncthreads();  // every wave is done reading the previous stage
-        // every load of the stage is issued before the first LDS store (one memory latency per stage, not one per chunk)
-        if constexpr (IN_U8) {
-            float4 pre[MAXLD];
+        if (stage) __syncthreads();  // every wave is done reading the previous stage
+        if constexpr (IN_U8) {  // the uint8 network input: every load of the stage is issued before the first LDS store
+            float4 pv[MAXLD];
             const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
-                const int pix = tid + k * 256;
+                const int pix = tid + k * NT;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pix < in_px) {
                     const int iy = (int)(((float)pix + 0.5f) * P.inv_twin), ix = pix - iy * TWin;
@@ -123,30 +205,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
                         if (P.cin == 4) v.w = P.lut[sp[3]];
                     }
                 }
-                pre[k] = v;
+                pv[k] = v;
             }
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
-                const int pix = tid + k * 256;
-                if (pix < in_px) *reinterpret_cast<float4 *>(smem + pix * PST) = pre[k];
-            }
-        } else {
-            u32x4 pre[MAXLD];
-#pragma unroll
-            for (int k = 0; k < MAXLD; ++k)
-                pre[k] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, goff[k] == NOPIX ? NOPIX : goff[k] + (unsigned)(stage * P.CK * 4), 0, 0);
-#pragma unroll
-            for (int k = 0; k < MAXLD; ++k) {
-                const int idx = tid + k * 256;
-                if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + (idx >> P.sh) * PST + (idx & (cpk - 1)) * 16) = pre[k];
+                const int pix = tid + k * NT;
+                if (pix < in_px) *reinterpret_cast<float4 *>(smem + pix * PST) = pv[k];
             }
         }
+        commit();
         __syncthreads();
-        const float *wst = wbase + (size_t)stage * P.kst * 256;
-        f32x4 wnext = *reinterpret_cast<const f32x4 *>(wst);
+        if (stage + 1 < P.nstage) fetch(stage + 1);  // in flight under this stage's MFMAs
         for (int ks = 0; ks < P.kst; ++ks) {
-            const f32x4 w = wnext;
-            wnext = *reinterpret_cast<const f32x4 *>(wst + (size_t)min(ks + 1, P.kst - 1) * 256);
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wfrag + ks * 1024);
             int q = ks * 4 + g;
             q = q < nq ? q : nq - 1;  // padding chunks: any valid address, their weights are zero
             int off;
@@ -157,9 +228,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
             } else {
                 off = q * 16;
             }
-            // the fragments go through in two halves: 4 * H MFMAs (>= 700 cycles) cover the other half's LDS reads, and only H operand
-            // vectors are live at a time
-            constexpr int H = MFM > 7 ? (MFM + 1) / 2 : MFM;
+            // the fragments go through in two halves: only H operand vectors are live at a time
+            constexpr int H = MFM > 4 ? (MFM + 1) / 2 : MFM;
 #pragma unroll
             for (int m0 = 0; m0 < MFM; m0 += H) {
                 f32x4 a[H];
@@ -169,20 +239,92 @@ __global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int i = 0; i < H; ++i)
-                        if (m0 + i < MFM) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[m0 + i], 0, 0, 0);
+                    for (int i = 0; i < H; ++i) {
+                        if (m0 + i < MFM - 1) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[m0 + i], 0, 0, 0);
+                        else if (m0 + i == MFM - 1) { if (lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[MFM - 1], 0, 0, 0); }
+                    }
             }
         }
     }
 
     // ---- epilogue: lane owns couts [cbase, cbase + 4) of its pixels
     const int cbase = F * 16 + g * 4;
+    if constexpr (TAIL > 0) {
+        // activated tile -> LDS [pixel][cout] (+16 B per row), then the second GEMM over it
+        constexpr int WC2 = TAIL, WP2 = NW / WC2, NFR = WP * MFM, MFM2 = (NFR + WP2 - 1) / WP2;
+        const int TPST = P.cout * 4 + 16;
+        __syncthreads();  // the k loop's LDS reads are done
+        {
+            const float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase);
+#pragma unroll
+            for (int mf = 0; mf < MFM; ++mf) {
+                const int p = (wp + WP * mf) * 16 + pl;
+                float v[4] = {acc[mf][0] + bv.x, acc[mf][1] + bv.y, acc[mf][2] + bv.z, acc[mf][3] + bv.w};
+                if (P.act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
+                }
+                if (cbase < P.cout) *reinterpret_cast<float4 *>(smem + p * TPST + cbase * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        const int wc2 = wave % WC2, wp2 = wave / WC2;
+        const float *w2base = P.w2 + (size_t)wc2 * P.kst2 * 256 + lane * 4;
+        f32x4 acc2[MFM2];
+#pragma unroll
+        for (int i = 0; i < MFM2; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 wn = *reinterpret_cast<const f32x4 *>(w2base);
+        for (int u = 0; u < P.kst2; ++u) {
+            const f32x4 w = wn;
+            wn = *reinterpret_cast<const f32x4 *>(w2base + (size_t)min(u + 1, P.kst2 - 1) * 256);
+            f32x4 a[MFM2];
+#pragma unroll
+            for (int i = 0; i < MFM2; ++i) {
+                const int f2 = wp2 + WP2 * i;
+                a[i] = *reinterpret_cast<const f32x4 *>(smem + ((f2 < NFR ? f2 : 0) * 16 + pl) * TPST + (u * 16 + g * 4) * 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MFM2; ++i)
+                    if (wp2 + WP2 * i < nfrag1) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc2[i], 0, 0, 0);
+        }
+        const int c2 = wc2 * 16 + g * 4;
+        if (c2 >= P.cout2) return;
+        const float4 bv2 = *reinterpret_cast<const float4 *>(P.b2 + c2);
+        const bool full2 = c2 + 4 <= P.cout2;
+#pragma unroll
+        for (int i = 0; i < MFM2; ++i) {
+            const int p = (wp2 + WP2 * i) * 16 + pl;
+            if (p >= npix) continue;
+            const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            if (oy >= P.Hout || ox >= P.Wout) continue;
+            const int64_t opix = (int64_t)oy * P.Wout + ox;
+            float v[4] = {acc2[i][0] + bv2.x, acc2[i][1] + bv2.y, acc2[i][2] + bv2.z, acc2[i][3] + bv2.w};
+            if (P.act2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
+            }
+            int64_t ob = b, opx = opix;
+            if (P.out2_hw > 0) { ob = opx / P.out2_hw; opx -= ob * P.out2_hw; }
+            float *op = P.out2 + ob * P.out2_bs + opx * P.out2_cs + P.out2_co + c2;
+            if (full2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
+                *reinterpret_cast<float4 *>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c2 + j < P.cout2) op[j] = v[j];
+            }
+        }
+        return;
+    }
     if (cbase >= P.cout) return;
     const float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase);  // bias is padded: always readable
     const bool full = cbase + 4 <= P.cout;
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) {
-        const int p = (wp * MFM + mf) * 16 + pl;
+        const int p = (wp + WP * mf) * 16 + pl;
         if (p >= npix) continue;
         const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
         const int oy = oy0 + ty, ox = ox0 + tx;
@@ -218,25 +360,30 @@ __global__ __launch_bounds__(256, 3) void k_conv_f32(const C32Params P) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+static constexpr int kNW = 8;  // waves per workgroup
 static int ilog2_(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 static int c32_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 4) + 3) / 4; }
-static int c32_mfm(int WC) { return WC == 4 ? 13 : (WC == 2 ? 7 : 4); }
+static int c32_mfm_max(int WC) { return WC == 4 ? 7 : (WC == 2 ? 4 : 2); }  // 224 / 256 / 256 pixels per tile
+static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
+static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
 
-Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8) {
+Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat) {
     Conv32Tiling t;
     t.WC = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
     if (in_u8) t.CK = 4;
     else {
-        const int cap = ks == 1 ? 32 : (stride == 2 ? 8 : 16);
+        const int cap = ks == 1 ? 32 : (stride == 2 ? 8 : 16);  // (1x1 with 64-channel stages: measured, no gain -- 18.05 -> 18.22 ms per 512 tiles)
         int ck = 4;
         while (ck * 2 <= cap && cin % (ck * 2) == 0) ck *= 2;
+        if (ks == 1 && !vcat && ck == 16 && cin % 48 == 0) ck = 48;  // 48- / 96-channel concats: one stage of three 16-channel groups instead of three stages of one k step
         t.CK = ck;
     }
-    const int WP = 4 / t.WC, MFM = c32_mfm(t.WC);
-    const int maxpix = 16 * WP * MFM;  // 208 / 224 / 256 pixels for WC = 4 / 2 / 1
+    const int WP = kNW / t.WC, MFMX = c32_mfm_max(t.WC);
+    const int maxpix = 16 * WP * MFMX;
+    const int chunk_cap = (vcat ? 4 : c32_maxld(ks, in_u8)) * kNW * 64;  // 16-B chunks one stage may hold
     if (ks == 1) {  // 1-D: the caller flattens batch x pixels
-        while (t.CK > 4 && (maxpix * (t.CK / 4) > 9 * 256 || (int64_t)maxpix * (t.CK * 4 + 16) > 64 * 1024)) t.CK /= 2;
-        t.TH = 1; t.TW = maxpix;
+        while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * c32_ksteps(1, t.CK) * 1024 > 78 * 1024)) t.CK /= 2;
+        t.TH = 1; t.TW = maxpix; t.MFM = MFMX;
         return t;
     }
     const int PST = t.CK * 4 + 16;
@@ -246,14 +393,21 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     int64_t best_cost = -1;
     for (int th = 1; th <= std::min(Hout, maxpix / t.TW); ++th) {
         const int64_t in_px = (int64_t)((th - 1) * stride + ks) * ((t.TW - 1) * stride + ks);
-        if (in_px * PST > 64 * 1024 || in_px * (t.CK / 4) > 9 * 256) break;
-        // every wave computes its full set of fragments whatever the tile holds: MFMA time ~ tiles x fragments per wave
-        const int mfm = (t.WC == 4 && th * t.TW <= 11 * 16) ? 11 : MFM;
-        const int64_t cost = (int64_t)((Hout + th - 1) / th) * tiles_x * mfm;
+        if (in_px * PST + t.WC * c32_ksteps(ks, t.CK) * 1024 > 78 * 1024 || in_px * (in_u8 ? 1 : t.CK / 4) > chunk_cap) break;
+        // time ~ tiles x (fragments of the busiest wave + the fixed cost of a stage: barriers + LDS commit, about one fragment's MFMAs)
+        const int mfm = std::max(((th * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
+        const int64_t cost = (int64_t)((Hout + th - 1) / th) * tiles_x * (mfm + 1);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_th = th; }
     }
     t.TH = best_th;
+    t.MFM = std::max(((t.TH * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
     return t;
+}
+
+bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2) {
+    if (cout1 != 16 * t.WC || (cout1 != 16 && cout1 != 32 && cout1 != 64)) return false;  // the whole producer in one workgroup
+    if (cout2 < 1 || cout2 > 64) return false;
+    return (size_t)16 * (kNW / t.WC) * t.MFM * (cout1 * 4 + 16) <= 80 * 1024;
 }
 
 std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks, const Conv32Tiling &t, const int *perm, bool in_u8) {
@@ -266,54 +420,85 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
     const int taps = ks * ks, nq = taps * cpk;
     std::vector<float> out((size_t)nfp * nstage * kst * 256, 0.f);
     size_t o = 0;
-    for (int F = 0; F < nfp; ++F)
+    for (int cb = 0; cb < nfp / t.WC; ++cb)  // [cout block][stage][fragment of the block][k step][lane][4]: a workgroup's stage is one contiguous run
         for (int st = 0; st < nstage; ++st)
-            for (int k = 0; k < kst; ++k)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int r = lane & 15, gq = lane >> 4;
-                    const int co = F * 16 + r;
-                    const int q = k * 4 + gq;
-                    for (int s = 0; s < 4; ++s, ++o) {
-                        if (q >= nq || co >= cout) continue;
-                        const int tap = q / cpk, c = st * CK + (q % cpk) * 4 + s;
-                        if (c >= cin) continue;
-                        const int src = perm ? perm[co] : co;
-                        out[o] = w[((size_t)src * cin + c) * taps + tap];
+            for (int wc = 0; wc < t.WC; ++wc)
+                for (int k = 0; k < kst; ++k)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int r = lane & 15, gq = lane >> 4;
+                        const int co = (cb * t.WC + wc) * 16 + r;
+                        const int q = k * 4 + gq;
+                        for (int s = 0; s < 4; ++s, ++o) {
+                            if (q >= nq || co >= cout) continue;
+                            const int tap = q / cpk, c = st * CK + (q % cpk) * 4 + s;
+                            if (c >= cin) continue;
+                            const int src = perm ? perm[co] : co;
+                            out[o] = w[((size_t)src * cin + c) * taps + tap];
+                        }
                     }
-                }
     return out;
 }
 
 size_t conv32_lds_bytes(const Conv32Launch &L) {
     const int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    return (size_t)THin * TWin * (L.CK * 4 + 16);
+    size_t lds = (((size_t)THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_ksteps(L.ks, L.CK) * 1024;  // activation tile + stage weights
+    if (L.tail_cout > 0) lds = std::max(lds, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
+    return lds;
 }
 
-template <int KS, int MFM, int WC>
-static hipError_t launch32_t(const Conv32Launch &L, const C32Params &P, dim3 grid, size_t lds, hipStream_t st) {
-    if (L.in_u8) {
-        if constexpr (KS == 3 && WC == 1) hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, true>), grid, dim3(256), lds, st, P);
-        else return hipErrorInvalidValue;
-    } else hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, false>), grid, dim3(256), lds, st, P);
+template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL>
+static hipError_t launch32_k(const C32Params &P, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;  // (per instantiation) up to 80 KiB of dynamic LDS: two workgroups per CU
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL>), grid, dim3(kNW * 64), lds, st, P);
     return hipGetLastError();
 }
 
+// the instantiated (KS, MFM, WC) x feature combinations; anything else is refused (the plan builder only asks for these)
+template <int KS, int MFM, int WC>
+static hipError_t launch32_f(const Conv32Launch &L, const C32Params &P, int tail_wc2, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.in_u8) {
+        if constexpr (KS == 3 && WC == 1) { if (!tail_wc2 && !L.up_c) return launch32_k<KS, MFM, WC, true, false, 0>(P, grid, lds, st); }
+        return hipErrorInvalidValue;
+    }
+    if (L.up_c > 0) {
+        if constexpr (KS == 1 && WC == 4) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0>(P, grid, lds, st); }
+        return hipErrorInvalidValue;
+    }
+    switch (tail_wc2) {
+        case 0: return launch32_k<KS, MFM, WC, false, false, 0>(P, grid, lds, st);
+        case 1: if constexpr (WC == 1 || WC == 4) return launch32_k<KS, MFM, WC, false, false, 1>(P, grid, lds, st); break;
+        case 2: if constexpr (WC == 2) return launch32_k<KS, MFM, WC, false, false, 2>(P, grid, lds, st); break;
+        case 4: if constexpr (WC == 4) return launch32_k<KS, MFM, WC, false, false, 4>(P, grid, lds, st); break;
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int KS>
-static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, dim3 grid, size_t lds, hipStream_t st) {
-    switch (L.WC) {
-        case 4:
-            if (L.TH * L.TW <= 11 * 16) return launch32_t<KS, 11, 4>(L, P, grid, lds, st);  // a whole 13 x 13 level: 169 pixels
-            return launch32_t<KS, 13, 4>(L, P, grid, lds, st);
-        case 2: return launch32_t<KS, 7, 2>(L, P, grid, lds, st);
-        case 1: return launch32_t<KS, 4, 1>(L, P, grid, lds, st);
+static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, int tail_wc2, dim3 grid, size_t lds, hipStream_t st) {
+    switch (L.WC * 16 + L.MFM) {
+        case 4 * 16 + 7: return launch32_f<KS, 7, 4>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 6: return launch32_f<KS, 6, 4>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 5: return launch32_f<KS, 5, 4>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 4: return launch32_f<KS, 4, 4>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 4: return launch32_f<KS, 4, 2>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 3: return launch32_f<KS, 3, 2>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 2: return launch32_f<KS, 2, 2>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 2: return launch32_f<KS, 2, 1>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 1: return launch32_f<KS, 1, 1>(L, P, tail_wc2, grid, lds, st);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
-    if (L.in.cpb || L.out.cpb || L.res.cpb) return hipErrorInvalidValue;  // plain NHWC only
+    if (L.in.cpb || L.out.cpb || L.res.cpb || L.in2.cpb || L.tail_out.cpb) return hipErrorInvalidValue;  // plain NHWC only
     if ((L.ks != 1 && L.ks != 3) || (L.WC != 1 && L.WC != 2 && L.WC != 4)) return hipErrorInvalidValue;
     C32Params P;
+    memset(&P, 0, sizeof P);
     P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
     P.out = (float *)L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
     P.res = (const float *)L.res.p; P.res_bs = L.res.bs; P.res_cs = L.res.cs; P.res_co = L.res.co;
@@ -321,9 +506,9 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout; P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act;
     P.flip_bgr = L.flip_bgr;
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2_(L.CK / 4);
-    if ((4 << P.sh) != L.CK) return hipErrorInvalidValue;
-    const int WP = 4 / L.WC;
-    if (L.TH * L.TW > 16 * WP * c32_mfm(L.WC) || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
+    if ((4 << P.sh) != L.CK && !(L.ks == 1 && L.CK == 48 && !L.up_c && !L.in_u8)) return hipErrorInvalidValue;
+    const int WP = kNW / L.WC;
+    if (L.MFM < 1 || L.MFM > c32_mfm_max(L.WC) || L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
     const int cin_eff = L.in_u8 ? 4 : L.cin;
     if (!L.in_u8 && (L.cin % L.CK || (L.in.cs & 3) || (L.in.co & 3))) return hipErrorInvalidValue;
     if (L.in_u8 && (L.CK != 4 || (L.cin != 3 && L.cin != 4) || !L.lut)) return hipErrorInvalidValue;
@@ -335,23 +520,180 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.ncb = (L.cout + 16 * L.WC - 1) / (16 * L.WC);
     if (ntiles < 1 || (ntiles + 7) / 8 * 8 * P.ncb >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
-    const int TWin = (L.TW - 1) * L.stride + L.ks;
+    const int TWin = (L.TW - 1) * L.stride + L.ks, THin = (L.TH - 1) * L.stride + L.ks;
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
     {
-        const int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 4;  // from the slice's first element to the end of the image
+        int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 4;  // from the slice's first element to the end of the image
+        if (L.up_c > 0) {  // virtual [upsample | skip] concat: 1-D 1x1 launches over plain NHWC sources only
+            if (L.ks != 1 || L.in_u8 || L.B != 1 || L.Hin != 1 || !L.in2.p || L.up_c % L.CK || L.up_c >= L.cin || (L.up_W & 1) || (L.up_HW % L.up_W) ||
+                ((L.up_HW / L.up_W) & 1) || L.Win % L.up_HW || (L.in2.cs & 3) || (L.in2.co & 3))
+                return hipErrorInvalidValue;
+            span = ((int64_t)(L.Win / 4) * L.in.cs - L.in.co) * 4;  // the low-resolution source
+            const int64_t s2 = ((int64_t)L.Win * L.in2.cs - L.in2.co) * 4;
+            if (s2 <= 0 || s2 >= (1ll << 32) - 65536) return hipErrorInvalidValue;
+            P.in2 = L.in2.p; P.in2_cs = L.in2.cs; P.in2_co = L.in2.co; P.in2_span_bytes = (unsigned)s2;
+            P.up_c = L.up_c; P.up_W = L.up_W; P.up_HW = L.up_HW;
+        }
         if (!L.in_u8 && (span <= 0 || span >= (1ll << 32) - 65536)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = L.in_u8 ? 0u : (unsigned)span;
-        if (L.in_u8 && (int64_t)((L.TH - 1) * L.stride + L.ks) * TWin > 5 * 256) return hipErrorInvalidValue;
+    }
+    if ((int64_t)THin * TWin * (L.in_u8 ? 1 : L.CK / 4) > (int64_t)(L.up_c > 0 ? 4 : c32_maxld(L.ks, L.in_u8)) * kNW * 64) return hipErrorInvalidValue;  // staging plan: chunks per thread
+    int tail_wc2 = 0;
+    if (L.tail_cout > 0) {
+        const Conv32Tiling t{L.TH, L.TW, L.CK, L.WC, L.MFM};
+        if (!conv32_tail_supported(t, L.cout, L.tail_cout) || P.ncb != 1 || !L.tail_w || !L.tail_b || !L.tail_out.p || L.res.p) return hipErrorInvalidValue;
+        tail_wc2 = L.tail_cout > 32 ? 4 : (L.tail_cout > 16 ? 2 : 1);
+        if (L.WC == 1 && tail_wc2 != 1) return hipErrorInvalidValue;
+        if (L.WC == 2 && tail_wc2 != 2) { if (tail_wc2 == 1) tail_wc2 = 2; else return hipErrorInvalidValue; }  // (a 16-cout tail behind a 32-cout layer: the second fragment is empty)
+        P.w2 = L.tail_w; P.b2 = L.tail_b; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs; P.out2_co = L.tail_out.co;
+        P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.act2 = L.tail_act; P.kst2 = L.cout / 16;
     }
     const size_t lds = conv32_lds_bytes(L);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    {
-        const int THin = (L.TH - 1) * L.stride + L.ks;
-        if ((int64_t)THin * TWin * (L.CK / 4) > 9 * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
-    }
+    if (lds > 80 * 1024 || P.kst > (L.ks == 3 ? 9 : 4)) return hipErrorInvalidValue;  // (kst bound: the weight-fetch plan of the kernel, MAXW)
     dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * P.ncb));
-    return L.ks == 3 ? launch32_wc<3>(L, P, grid, lds, st) : launch32_wc<1>(L, P, grid, lds, st);
+    return L.ks == 3 ? launch32_wc<3>(L, P, tail_wc2, grid, lds, st) : launch32_wc<1>(L, P, tail_wc2, grid, lds, st);
+}
+
+// ------------------------------------------------------------------------------------------------ network input layer as row stripes
+// model.0 (Conv 3x3 s2 on the uint8 tile, CIN = 3 or 4, 16 * NF couts) with the predictor's preprocess fused in (`im.float() / 255` = the
+// 256-entry table, BGR -> RGB folded into the weight order).  The generic kernel pads the 3 input channels to 4-channel chunks per tap
+// (K = 48 of which 27 are real) and converts each byte once per tap; here a workgroup owns 4 output rows x the full width:
+//   * the 9 input rows are whole contiguous runs: 16-byte loads, table look-up, fp32 image in LDS ([row][x + 1][CIN], column 0 = the
+//     zero padding, row -1 of the first stripe = zeros);
+//   * k = (ky, kx, c) runs densely over the 9 * CIN taps (27 -> 28 or 36): one v_mfma_f32_16x16x4_f32 per 4 k values; the B operand
+//     of lane (pixel j, k slot g) at step t is ONE ds_read_b32 at pixel base + koff[t] (per-lane constants), the A operands (weights)
+//     stay in registers for the whole kernel;
+//   * a wave owns one output row and walks its fragments two at a time (independent accumulators: no dependent-issue stall); a lane's
+//     four couts are one float4 store and a wave instruction covers 16 pixels x 64 contiguous bytes.
+struct Stem32Params {
+    const uint8_t *in; int64_t in_bs;
+    float *out; int64_t out_bs; int out_cs, out_co;
+    const float *wA, *bias, *lut;
+    int Hin, Win, Hout, Wout, act, RS;
+};
+
+template <int CIN, int NF>
+__global__ __launch_bounds__(256) void k_stem_f32(const Stem32Params P) {
+    extern __shared__ __attribute__((aligned(16))) float sst[];
+    constexpr int K = 9 * CIN, KST = (K + 3) / 4, R = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int stripes = P.Hout / R;
+    const int b = blockIdx.x / stripes, oy0 = (blockIdx.x % stripes) * R;
+    const int RS = P.RS, rowb = P.Win * CIN, dpr = rowb >> 2;  // floats per LDS row; bytes / dwords per input row
+    float *slut = sst + (2 * R + 1) * RS;
+    slut[tid] = P.lut[tid];
+    // LDS row: floats [0, 4) = left margin (x = -1 lives in [4 - CIN, 4): the zero padding), pixel x at 4 + x * CIN -- the image part is
+    // 16-byte aligned, so that a lane converts ONE dword of the tile (4 bytes) into ONE ds_write_b128 and neighbouring lanes write
+    // neighbouring 16 bytes (a lane per 16-byte chunk wrote 64-byte-strided dwords: 16 lanes per bank)
+    if (tid < (2 * R + 1) * 4) sst[(tid >> 2) * RS + (tid & 3)] = 0.f;
+    __syncthreads();
+    const int iy0 = 2 * oy0 - 1;
+    const uint8_t *src = P.in + (int64_t)b * P.in_bs;
+    for (int i = tid; i < (2 * R + 1) * dpr; i += 256) {
+        const int lr = i / dpr, d = i - lr * dpr;
+        const int iy = iy0 + lr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < P.Hin) {
+            const unsigned wv = *reinterpret_cast<const unsigned *>(src + (int64_t)iy * rowb + d * 4);
+            v = make_float4(slut[wv & 255u], slut[(wv >> 8) & 255u], slut[(wv >> 16) & 255u], slut[wv >> 24]);
+        }
+        *reinterpret_cast<float4 *>(sst + lr * RS + 4 + d * 4) = v;
+    }
+    // per-lane constants: weights (A operand: cout = lane & 15 of fragment nf, k = 4 t + g) and the LDS offset of tap k
+    float wA[NF][KST];
+    int koff[KST];
+#pragma unroll
+    for (int t = 0; t < KST; ++t) {
+        const int k = 4 * t + g;
+        const int tap = k / CIN, c = k - tap * CIN;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        koff[t] = (4 - CIN) + (k < K ? ky * RS + kx * CIN + c : 0);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) wA[nf][t] = P.wA[(nf * KST + t) * 64 + lane];
+    }
+    float4 bv[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) bv[nf] = *reinterpret_cast<const float4 *>(P.bias + nf * 16 + 4 * g);
+    __syncthreads();
+    const int r = wave, oy = oy0 + r;
+    const int nfr = P.Wout >> 4;
+    float *orow = P.out + (int64_t)b * P.out_bs + (int64_t)oy * P.Wout * P.out_cs + P.out_co + 4 * g;
+    for (int f0 = 0; f0 < nfr; f0 += 2) {
+        const bool two = f0 + 1 < nfr;  // (wave-uniform)
+        const int pb0 = 2 * r * RS + 2 * (16 * f0 + j) * CIN, pb1 = two ? pb0 + 32 * CIN : pb0;
+        f32x4 acc0[NF], acc1[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) { acc0[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float b0[KST], b1[KST];  // every operand read is issued before the first MFMA: one LDS latency per fragment pair, not one per k step
+#pragma unroll
+        for (int t = 0; t < KST; ++t) { b0[t] = sst[pb0 + koff[t]]; b1[t] = sst[pb1 + koff[t]]; }
+#pragma unroll
+        for (int t = 0; t < KST; ++t) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                acc0[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[nf][t], b0[t], acc0[nf], 0, 0, 0);
+                acc1[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[nf][t], b1[t], acc1[nf], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            float *op = orow + (int64_t)(16 * (f0 + h) + j) * P.out_cs;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const f32x4 a = h ? acc1[nf] : acc0[nf];
+                float v[4] = {a[0] + bv[nf].x, a[1] + bv[nf].y, a[2] + bv[nf].z, a[3] + bv[nf].w};
+                if (P.act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = silu32(v[q]);
+                }
+                *reinterpret_cast<float4 *>(op + nf * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+static int stem32_rs(int Win, int cin) { return (4 + Win * cin + 3) & ~3; }
+
+bool stem32_supported(int cin, int cout, int ks, int stride, int Hin, int Win) {
+    if (ks != 3 || stride != 2 || (cin != 3 && cin != 4) || (cout != 16 && cout != 32)) return false;
+    if (Hin % 8 || Win % 32) return false;  // 4-row stripes of the output, 16-pixel fragments, 16-byte input chunks
+    return (size_t)(9 * stem32_rs(Win, cin) + 256) * 4 <= 64 * 1024;
+}
+
+// [fragment nf][k step t][lane]: weight of cout 16 nf + (lane & 15) for k = 4 t + (lane >> 4), k = (ky * 3 + kx) * cin + c over the
+// channels AS STORED in the tile (flip_bgr: stored BGR, the conv's channel order is RGB)
+std::vector<float> pack_stem32_weights(const float *w, int cout, int cin, bool flip_bgr) {
+    const int K = 9 * cin, KST = (K + 3) / 4, NF = cout / 16;
+    std::vector<float> out((size_t)NF * KST * 64, 0.f);
+    for (int nf = 0; nf < NF; ++nf)
+        for (int t = 0; t < KST; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 4 * t + (lane >> 4), co = nf * 16 + (lane & 15);
+                if (k >= K) continue;
+                const int tap = k / cin, c = k % cin;
+                const int cs = (flip_bgr && c < 3) ? 2 - c : c;
+                out[((size_t)nf * KST + t) * 64 + lane] = w[((size_t)co * cin + cs) * 9 + tap];
+            }
+    return out;
+}
+
+hipError_t launch_stem32(const Stem32Launch &L, hipStream_t st) {
+    if (!stem32_supported(L.cin, L.cout, 3, 2, L.Hin, L.Win) || L.out.cpb || (L.out.cs & 3) || (L.out.co & 3) || !L.lut) return hipErrorInvalidValue;
+    Stem32Params P;
+    P.in = L.in; P.in_bs = (int64_t)L.Hin * L.Win * L.cin;
+    P.out = (float *)L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
+    P.wA = L.wpk; P.bias = L.bias; P.lut = L.lut;
+    P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hin / 2; P.Wout = L.Win / 2; P.act = L.act; P.RS = stem32_rs(L.Win, L.cin);
+    const size_t lds = (size_t)(9 * P.RS + 256) * 4;
+    const dim3 grid((unsigned)(L.B * (P.Hout / 4)));
+    if (L.cin == 3 && L.cout == 16) hipLaunchKernelGGL((k_stem_f32<3, 1>), grid, dim3(256), lds, st, P);
+    else if (L.cin == 4 && L.cout == 16) hipLaunchKernelGGL((k_stem_f32<4, 1>), grid, dim3(256), lds, st, P);
+    else if (L.cin == 3 && L.cout == 32) hipLaunchKernelGGL((k_stem_f32<3, 2>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_stem_f32<4, 2>), grid, dim3(256), lds, st, P);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ the non-GEMM layers in fp32
@@ -389,6 +731,60 @@ __global__ __launch_bounds__(256) void k_dwconv3_f32(TensorRef in, TensorRef out
         v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
     }
     *reinterpret_cast<float4 *>((float *)out.p + (int64_t)b * out.bs + opix * out.cs + out.co + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Column-walking form of the same layer: a thread owns (x, 4 channels) and walks R consecutive output rows with a three-row window of
+// the input in registers, so that every input chunk is loaded 3 times (x - 1, x, x + 1: neighbouring lanes, the same cache lines)
+// instead of 9 and the nine tap weights are read once per thread.  Taps are summed in the same (ky, kx) order as above and the zero
+// padding contributes exact zeros: results are bit-identical to k_dwconv3_f32.
+template <int R>
+__global__ __launch_bounds__(256) void k_dwconv3_col_f32(TensorRef in, TensorRef out, TensorRef res, const float *__restrict__ w, const float *__restrict__ bias,
+                                                        int B, int H, int W, int C, int act) {
+    const int c4n = C >> 2, segs = (H + R - 1) / R;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * segs * W * c4n) return;
+    const int c4 = (int)(idx % c4n);
+    int64_t r_ = idx / c4n;
+    const int x = (int)(r_ % W); r_ /= W;
+    const int seg = (int)(r_ % segs), b = (int)(r_ / segs);
+    const int y0 = seg * R;
+    const float *ip = (const float *)in.p + (int64_t)b * in.bs + in.co + c4 * 4;
+    float4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4 *>(w + t * C + c4 * 4);
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? *reinterpret_cast<const float4 *>(ip + ((int64_t)yy * W + xx) * in.cs) : z; };
+    float4 r0[3], r1[3], r2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r0[k] = ld(y0 - 1, x + k - 1); r1[k] = ld(y0, x + k - 1); }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int y = y0 + i;
+        if (y >= H) break;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r2[k] = ld(y + 1, x + k - 1);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a[0] = fmaf(r0[k].x, wv[k].x, a[0]); a[1] = fmaf(r0[k].y, wv[k].y, a[1]); a[2] = fmaf(r0[k].z, wv[k].z, a[2]); a[3] = fmaf(r0[k].w, wv[k].w, a[3]); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a[0] = fmaf(r1[k].x, wv[3 + k].x, a[0]); a[1] = fmaf(r1[k].y, wv[3 + k].y, a[1]); a[2] = fmaf(r1[k].z, wv[3 + k].z, a[2]); a[3] = fmaf(r1[k].w, wv[3 + k].w, a[3]); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a[0] = fmaf(r2[k].x, wv[6 + k].x, a[0]); a[1] = fmaf(r2[k].y, wv[6 + k].y, a[1]); a[2] = fmaf(r2[k].z, wv[6 + k].z, a[2]); a[3] = fmaf(r2[k].w, wv[6 + k].w, a[3]); }
+        float v[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
+        }
+        const int64_t opix = (int64_t)y * W + x;
+        if (res.p) {
+            const float4 rv = *reinterpret_cast<const float4 *>((const float *)res.p + (int64_t)b * res.bs + opix * res.cs + res.co + c4 * 4);
+            v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
+        }
+        *reinterpret_cast<float4 *>((float *)out.p + (int64_t)b * out.bs + opix * out.cs + out.co + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_maxpool5_f32(TensorRef in, TensorRef out, int B, int H, int W, int C) {
@@ -476,12 +872,157 @@ __global__ __launch_bounds__(64) void k_attention_f32(TensorRef qkv, TensorRef o
         *reinterpret_cast<float4 *>(op + c * 4) = make_float4(acc[4 * c] / den, acc[4 * c + 1] / den, acc[4 * c + 2] / den, acc[4 * c + 3] / den);
 }
 
+// The same attention core on the exact-f32 matrix instruction (N <= 192 tokens).  One workgroup (4 waves) per (tile, head); K [NP][36]
+// and V [NP][64] of all tokens in LDS (NP = N rounded up to 16, rows past N are zeros); a wave owns 16-query fragments.
+//   S^T = K Q^T:  A = 16 keys x 4 dims, B = 4 dims x 16 queries -> a lane holds, for ITS query (lane & 15), the scores of the keys
+//                 16 f + 4 g + r (f = key fragment, g = lane >> 4, r = register): the softmax reductions are in-lane + two xor-shuffles
+//   O^T = V^T P^T: the k step (f, r) takes the keys {16 f + 4 g + r}: the B operand IS register r of score fragment f (no shuffle, no LDS
+//                 round trip), the A operand row i carries the value dims 4 i + df for the four output fragments df (ONE ds_read_b128 of
+//                 V[key][4 i ..] feeds four MFMAs), so that a lane ends with the 16 contiguous output dims 16 g .. 16 g + 15 of its query.
+// Two-pass softmax (max, then exp / sum) and an IEEE division at the end, like the scalar kernel above.
+template <int NFMAX>
+__global__ __launch_bounds__(256) void k_attention_mfma_f32(TensorRef qkv, TensorRef out, int N, int nh, float scale) {
+    constexpr int KD = 32, HD = 64, KST = KD + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm32[];
+    const int NP = (N + 15) & ~15, nf = NP >> 4;
+    float *sk = sm32, *sv = sm32 + (size_t)NP * KST;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    const float *base = (const float *)qkv.p + (int64_t)b * qkv.bs + qkv.co;
+    for (int i = threadIdx.x; i < NP * (KD / 4); i += 256) {
+        const int n = i / (KD / 4), c = i % (KD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) v = *reinterpret_cast<const float4 *>(base + (int64_t)n * qkv.cs + nh * KD + h * KD + c * 4);
+        *reinterpret_cast<float4 *>(sk + n * KST + c * 4) = v;
+    }
+    for (int i = threadIdx.x; i < NP * (HD / 4); i += 256) {
+        const int n = i / (HD / 4), c = i % (HD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) v = *reinterpret_cast<const float4 *>(base + (int64_t)n * qkv.cs + 2 * nh * KD + h * HD + c * 4);
+        *reinterpret_cast<float4 *>(sv + n * HD + c * 4) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    for (int qf = wave; qf < nf; qf += 4) {
+        const int qrow = min(16 * qf + j, N - 1);
+        const float *qp = base + (int64_t)qrow * qkv.cs + h * KD + 4 * g;
+        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(qp), q1 = *reinterpret_cast<const f32x4 *>(qp + 16);
+        f32x4 sc[NFMAX];
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f) sc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f0 = 0; f0 < NFMAX; f0 += 4) {  // four key fragments at a time: their MFMAs interleave (no back-to-back dependent issue)
+            f32x4 k0[4], k1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i < nf ? f0 + i : 0;
+                const float *kp = sk + (16 * f + j) * KST + 4 * g;
+                k0[i] = *reinterpret_cast<const f32x4 *>(kp);
+                k1[i] = *reinterpret_cast<const f32x4 *>(kp + 16);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (f0 + i < NFMAX && f0 + i < nf) sc[f0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[i][s], q0[s], sc[f0 + i], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (f0 + i < NFMAX && f0 + i < nf) sc[f0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[i][s], q1[s], sc[f0 + i], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (f < nf && 16 * f + 4 * g + r < N) ? sc[f][r] * scale : -INFINITY;
+                sc[f][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(sc[f][r] - mx);  // masked keys: exp(-inf) = 0
+                sc[f][r] = pv;
+                den += pv;
+            }
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        f32x4 o[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f) {
+            if (f < nf) {  // (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(sv + (16 * f + 4 * g + r) * HD + 4 * j);
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) o[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[df], sc[f][r], o[df], 0, 0, 0);
+                }
+            }
+        }
+        const int n = 16 * qf + j;
+        if (n < N) {
+            float *op = (float *)out.p + (int64_t)b * out.bs + (int64_t)n * out.cs + out.co + h * HD + 16 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4 *>(op + 4 * r) = make_float4(o[0][r] / den, o[1][r] / den, o[2][r] / den, o[3][r] / den);
+        }
+    }
+}
+
+// SPPF: the three chained 5x5 stride-1 max pools of `cat` = [x | m1 | m2 | m3] in one launch: a workgroup owns (image, 32 channels); the
+// plane lives in LDS; each pass = 1x5 max of the 5x1 max (window clipped at the border = -inf padding); every pass's result is stored
+// to its channel slice and is the next pass's input.
+__global__ __launch_bounds__(256) void k_sppf_pools_f32(TensorRef cat, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float4 sp32[];  // two planes [H*W][8 chunks of 4 channels]
+    const int groups = C >> 5;
+    const int b = blockIdx.x / groups, cg = blockIdx.x % groups;
+    const int n = H * W * 8;
+    float *base = (float *)cat.p + (int64_t)b * cat.bs + cat.co + cg * 32;
+    float4 *cur = sp32, *tmp = sp32 + n;
+    for (int i = threadIdx.x; i < n; i += 256) cur[i] = *reinterpret_cast<const float4 *>(base + (int64_t)(i >> 3) * cat.cs + (i & 7) * 4);
+    __syncthreads();
+    auto mx4 = [](float4 a, float4 c) { return make_float4(fmaxf(a.x, c.x), fmaxf(a.y, c.y), fmaxf(a.z, c.z), fmaxf(a.w, c.w)); };
+    for (int pass = 1; pass <= 3; ++pass) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int pix = i >> 3, c = i & 7;
+            const int y = pix / W, x = pix - y * W;
+            float4 m = cur[i];
+            for (int xx = max(0, x - 2); xx <= min(W - 1, x + 2); ++xx) m = mx4(m, cur[(y * W + xx) * 8 + c]);
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int pix = i >> 3, c = i & 7;
+            const int y = pix / W, x = pix - y * W;
+            float4 m = tmp[i];
+            for (int yy = max(0, y - 2); yy <= min(H - 1, y + 2); ++yy) m = mx4(m, tmp[(yy * W + x) * 8 + c]);
+            cur[i] = m;  // (element i of `cur` is read only by this thread in this loop: in place)
+            *reinterpret_cast<float4 *>(base + (int64_t)pass * C + (int64_t)pix * cat.cs + c * 4) = m;
+        }
+        __syncthreads();
+    }
+}
+
 static inline unsigned blocks_for32(int64_t n) { return (unsigned)((n + 255) / 256); }
 static bool plain4(const TensorRef &t) { return t.cpb == 0 && (t.cs & 3) == 0 && (t.co & 3) == 0; }
 
 hipError_t launch_dwconv3_f32(const TensorRef &in, const TensorRef &out, const TensorRef &res, const float *w, const float *bias, int B, int H, int W, int C,
                               int act, hipStream_t st) {
     if (C % 4 || !plain4(in) || !plain4(out) || (res.p && !plain4(res))) return hipErrorInvalidValue;
+    // the zero-padded taps of the simple kernel are skipped, here they are fma(0, w, a): the same value unless a weight is inf / nan
+    if (H >= 8) {
+        constexpr int R = 13;
+        hipLaunchKernelGGL((k_dwconv3_col_f32<R>), dim3(blocks_for32((int64_t)B * ((H + R - 1) / R) * W * (C / 4))), dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_dwconv3_f32, dim3(blocks_for32((int64_t)B * H * W * (C / 4))), dim3(256), 0, st, in, out, res, w, bias, B, H, W, C, act);
     return hipGetLastError();
 }
@@ -498,8 +1039,30 @@ hipError_t launch_upsample2_f32(const TensorRef &in, const TensorRef &out, int B
     return hipGetLastError();
 }
 
-hipError_t launch_attention_f32(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, hipStream_t st) {
+hipError_t launch_sppf_pools_f32(const TensorRef &cat, int B, int H, int W, int C, hipStream_t st) {
+    const size_t lds = (size_t)2 * H * W * 128;
+    if (C % 32 || !plain4(cat) || lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sppf_pools_f32, dim3((unsigned)(B * (C / 32))), dim3(256), lds, st, cat, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_f32(const TensorRef &qkv, const TensorRef &out, int B, int N, int nh, int kd, int hd, bool use_mfma, hipStream_t st) {
     if (kd != 32 || hd != 64 || !plain4(qkv) || !plain4(out) || N < 1) return hipErrorInvalidValue;
+    if (use_mfma && N <= 192) {
+        const int NP = (N + 15) & ~15;
+        const size_t lds_m = sizeof(float) * ((size_t)NP * 36 + (size_t)NP * 64);  // <= 75 KiB
+        static bool attr_m = false;
+        if (!attr_m) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_attention_mfma_f32<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_attention_mfma_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+            attr_m = true;
+        }
+        const float scale_m = (float)(1.0 / sqrt((double)kd));
+        if (NP <= 64) hipLaunchKernelGGL((k_attention_mfma_f32<4>), dim3((unsigned)(B * nh)), dim3(256), lds_m, st, qkv, out, N, nh, scale_m);
+        else hipLaunchKernelGGL((k_attention_mfma_f32<12>), dim3((unsigned)(B * nh)), dim3(256), lds_m, st, qkv, out, N, nh, scale_m);
+        return hipGetLastError();
+    }
     const size_t lds = sizeof(float) * ((size_t)N * 32 + (size_t)N * 64);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;

@@ -13,6 +13,7 @@
 
 #include "ctx.h"
 #include "geom_device.h"
+#include "post_device.h"
 
 namespace obb {
 
@@ -626,8 +627,10 @@ static constexpr int kSegWords = kSegMax / 64;
 // over all lanes (a row-per-thread loop would leave most of the group idle behind the few crowded rows).
 static constexpr int kSegPairCap = 12288;
 
+// Segment `seg` = rows [seg_lo[seg], seg_hi[seg]) (a prefix-offset array passes (off, off + 1); the fused per-tile path passes fixed-stride
+// slots with their fill counts).
 __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
-                                                        const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
+                                                        const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
                                                         double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
                                                         int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto) {
     __shared__ double skey[kSegMax];
@@ -639,11 +642,13 @@ __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restric
     __shared__ unsigned int npairs_s;
     const int NT = 1024;
     int seg = blockIdx.x;
-    int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     int n = s1 - s0;
     if (n <= skip_upto) { if (n <= 0 && skip_upto == 0 && threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }  // (short ones: k_merge_segments_wave)
-    if (n > kSegMax) {  // caller promised segments <= kSegMax; flag and leave outputs untouched
+    if (n > kSegMax) {  // too long for LDS: flag it and write a DEFINED result (identity order, nothing kept); outside a stream capture the
+        // host then reruns such segments through the dense path, inside one (no host read possible) the caller sees them dropped, not garbage
         if (threadIdx.x == 0) atomicExch(status, 1);
+        for (int t = threadIdx.x; t < n; t += NT) { order[s0 + t] = s0 + t; keep[s0 + t] = 0; }
         return;
     }
     if (threadIdx.x == 0) npairs_s = 0;
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restric
 // segments at once instead of one 1024-thread workgroup each.  Same phases and the same arithmetic as k_merge_segments.
 static constexpr int kSegWave = 64;
 __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
-                                                           const double *__restrict__ conf, const int32_t *__restrict__ seg_off,
+                                                           const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
                                                            double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
                                                            int32_t *__restrict__ n_keep) {
     __shared__ double skey[kSegWave];
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__rest
     __shared__ unsigned short spairs[kSegWave * (kSegWave - 1) / 2];
     __shared__ unsigned int npairs_s;
     const int seg = blockIdx.x, t = threadIdx.x;
-    const int32_t s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    const int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     const int n = s1 - s0;
     if (n <= 0) { if (t == 0 && n_keep) n_keep[seg] = 0; return; }
     if (n > kSegWave) return;  // k_merge_segments takes it
@@ -1045,23 +1050,182 @@ __global__ __launch_bounds__(256) void k_tile_post(const float *__restrict__ lp,
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int t = det_tile[i];
-    int x = rects[4 * t], y = rects[4 * t + 1], x2 = rects[4 * t + 2], y2 = rects[4 * t + 3];
-    double p[8], g[8];
-    for (int k = 0; k < 8; ++k) p[k] = (double)lp[i * 8 + k];  // float(v) widening, Detect_OBB.py:229
-    for (int k = 0; k < 4; ++k) { g[2 * k] = p[2 * k] + (double)x; g[2 * k + 1] = p[2 * k + 1] + (double)y; }  // :233-234
+    double g[8], a;
+    bool in;
+    tile_post_row(lp + i * 8, cls[i], rects[4 * t], rects[4 * t + 1], rects[4 * t + 2], rects[4 * t + 3], margin, strike_cls, g, a, in);  // post_device.h
     for (int k = 0; k < 8; ++k) gb[i * 8 + k] = g[k];
-    double cx = (g[0] + g[2] + g[4] + g[6]) / 4.0, cy = (g[1] + g[3] + g[5] + g[7]) / 4.0;  // :163-164
-    double cxr = cx - (double)x, cyr = cy - (double)y, m = (double)margin;
-    double cw = (double)(x2 - x), ch = (double)(y2 - y);
-    bool in = true;
-    if (margin > 0) in = (m <= cxr && cxr <= (cw - m)) && (m <= cyr && cyr <= (ch - m));  // :174, :242
     inside[i] = (uint8_t)in;
-    double a = 0.0;
-    if (cls[i] == strike_cls) {  // :251-254 uses the LOCAL points
-        a = atan2(p[6] - p[0], p[7] - p[1]) * (180.0 / 3.141592653589793);
-        a = (a > 0) ? 180 - a : fabs(a);
-    }
     angle[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------ fused per-tile survivors path
+// obb_tile_survivors: everything between the NMS output and the exchange records on the device, tile by tile, with no host-visible
+// count in between (the stand-alone chain glued k_results / k_tile_post / the segment merge with host-side compactions).
+struct SurvStage {  // fixed-stride staging rows: slot t * md + j = the j-th detection of tile t that passed the border filter
+    double *gb;      // [B * md][8] global corners
+    double *conf;    // [B * md] float32 confidence widened (the merge's sort key, exactly float(det.conf[0]))
+    int32_t *cls;    // [B * md]
+    float *pts;      // [B * md][8] local corners
+    float *conf32;   // [B * md]
+    int32_t *lo, *hi;  // [B] segment bounds in slot space
+};
+
+// One workgroup per tile: construct_result + the per-detection body for each of its NMS rows (post_device.h: the same arithmetic as
+// k_results / k_tile_post), ordered compaction of the rows inside the border (ballot + per-wave sums: NMS order is kept).
+__global__ __launch_bounds__(256) void k_tile_stage(const float *__restrict__ det, const int32_t *__restrict__ count, int md, const float *__restrict__ lb,
+                                                   const int32_t *__restrict__ tile_ids, const int32_t *__restrict__ rects, int margin, int strike_cls,
+                                                   SurvStage S) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(count[t], md);
+    const int tile = tile_ids[t];
+    const int x = rects[4 * tile], y = rects[4 * tile + 1], x2 = rects[4 * tile + 2], y2 = rects[4 * tile + 3];
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int k = k0 + tid;
+        bool in = false;
+        float p[8];
+        double g[8], ang;
+        int c = 0;
+        float cf = 0.f;
+        if (k < n) {
+            const float *d = det + ((int64_t)t * md + k) * 7;
+            results_row(d, lb ? lb + (int64_t)t * 3 : nullptr, nullptr, p);
+            c = (int)d[5];
+            cf = d[4];
+            tile_post_row(p, c, x, y, x2, y2, margin, strike_cls, g, ang, in);
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (in) {
+            const int64_t slot = (int64_t)t * md + before + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int q = 0; q < 8; ++q) { S.gb[slot * 8 + q] = g[q]; S.pts[slot * 8 + q] = p[q]; }
+            S.cls[slot] = c; S.conf[slot] = (double)cf; S.conf32[slot] = cf;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) { S.lo[t] = t * md; S.hi[t] = t * md + base_s; }
+}
+
+// exclusive scan of cnt[0..n) -> off[0..n], off[n] = total (also stored to *total); one workgroup
+__global__ __launch_bounds__(1024) void k_scan_counts(const int32_t *__restrict__ cnt, int n, int32_t *__restrict__ off, int32_t *__restrict__ total) {
+    __shared__ int wtot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const int v = i < n ? cnt[i] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        if (i < n) off[i] = before + incl - v;
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wtot[w]; base_s += s; }
+        __syncthreads();
+    }
+    if (tid == 0) { off[n] = base_s; if (total) *total = base_s; }
+}
+
+// One wave per tile: the kept rows of its merged segment, in merge (confidence) order, as 48-byte exchange records at off[tile]
+__global__ __launch_bounds__(64) void k_tile_emit(SurvStage S, const int32_t *__restrict__ order, const uint8_t *__restrict__ keep, const int32_t *__restrict__ off,
+                                                 const int32_t *__restrict__ tile_ids, int32_t *__restrict__ rec) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int s0 = S.lo[t], n = S.hi[t] - s0;
+    int base = off[t];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool k = i < n && keep[s0 + i];
+        const unsigned long long bal = __ballot(k);
+        if (k) {
+            const int src = order[s0 + i];
+            int32_t *r = rec + ((int64_t)base + __popcll(bal & ((1ull << lane) - 1ull))) * 12;
+            r[0] = tile_ids[t]; r[1] = S.cls[src]; r[2] = __float_as_int(S.conf32[src]); r[3] = 0;
+            for (int q = 0; q < 8; ++q) r[4 + q] = __float_as_int(S.pts[(int64_t)src * 8 + q]);
+        }
+        base += __popcll(bal);
+    }
+}
+
+// Ordered compaction of a merge result: out row r = input row order[i] for the r-th kept sorted position i.  One workgroup walks the
+// sorted positions in chunks of 1024 (ballot + per-wave sums), so the kept rows come out in merge order; *n_out = their number.
+__global__ __launch_bounds__(1024) void k_select_kept(const int32_t *__restrict__ order, const uint8_t *__restrict__ keep, int64_t n,
+                                                     const double *__restrict__ boxes, const int32_t *__restrict__ cls, const double *__restrict__ conf,
+                                                     const double *__restrict__ angle, double *__restrict__ oboxes, int32_t *__restrict__ ocls,
+                                                     double *__restrict__ oconf, double *__restrict__ oangle, int32_t *__restrict__ n_out) {
+    __shared__ int wtot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        const bool k = i < n && keep[i];
+        const unsigned long long bal = __ballot(k);
+        if (lane == 0) wtot[wave] = __popcll(bal);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        if (k) {
+            const int64_t src = order[i], dst = before + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int q = 0; q < 8; ++q) oboxes[dst * 8 + q] = boxes[src * 8 + q];
+            ocls[dst] = cls[src]; oconf[dst] = conf[src];
+            if (angle) oangle[dst] = angle[src];
+        }
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wtot[w]; base_s += s; }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = base_s;
+}
+
+// exchange records -> SoA detections: global float64 corners + strike angle re-derived from the float32 local corners and the integer
+// tile offset (exact), confidence widened to float64 (what float(det.conf[0]) gives): the consumer side of the 48-byte records
+__global__ __launch_bounds__(256) void k_records_to_dets(const int32_t *__restrict__ rec, int64_t n, const int32_t *__restrict__ rects, int strike_cls,
+                                                        double *__restrict__ gb, int32_t *__restrict__ cls, double *__restrict__ conf, double *__restrict__ angle) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *r = rec + i * 12;
+    const int t = r[0], c = r[1];
+    float lp[8];
+    for (int q = 0; q < 8; ++q) lp[q] = __int_as_float(r[4 + q]);
+    double g[8], a;
+    bool in;
+    tile_post_row(lp, c, rects[4 * t], rects[4 * t + 1], rects[4 * t + 2], rects[4 * t + 3], 0, strike_cls, g, a, in);
+    for (int q = 0; q < 8; ++q) gb[i * 8 + q] = g[q];
+    cls[i] = c; conf[i] = (double)__int_as_float(r[2]); angle[i] = a;
+}
+
+// valid rows of a fixed-capacity all-gather buffer [world][cap + 1][12] (row 0 of a rank's block: its count) -> dense [total][12] in
+// rank order; counts_out[w] = rank w's count (may exceed cap: the caller then repeats the exchange), counts_out[world] = rows written
+__global__ __launch_bounds__(256) void k_gather_compact(const int32_t *__restrict__ recv, int world, int cap, int32_t *__restrict__ out, int32_t *__restrict__ counts_out) {
+    const int w = blockIdx.y;
+    int before = 0, mine = 0, total = 0;
+    for (int r = 0; r < world; ++r) {
+        const int c = min(recv[(int64_t)r * (cap + 1) * 12], cap);
+        if (r < w) before += c;
+        if (r == w) mine = c;
+        total += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counts_out[w] = recv[(int64_t)w * (cap + 1) * 12];
+        if (w == 0) counts_out[world] = total;
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 16-byte piece i of this rank's rows (3 per row)
+    if (i >= (int64_t)mine * 3) return;
+    const int4 *src = reinterpret_cast<const int4 *>(recv + ((int64_t)w * (cap + 1) + 1) * 12);
+    reinterpret_cast<int4 *>(out + (int64_t)before * 12)[i] = src[i];
 }
 
 __global__ void k_add_offset(int32_t *v, int64_t n, int32_t add) {
@@ -1223,15 +1387,16 @@ int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, co
     int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
     if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
     OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, thr, order, keep, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr, order, keep, (int32_t *)nullptr);
     if (n > kSegWave)  // (some segment may be longer than a wave takes)
-        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, thr,
+        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr,
                            order, keep, (int32_t *)nullptr, status, kSegWave);
     OBB_LAUNCH_CHECK(ctx);
     if (n <= kSegMax) return OBB_OK;  // no segment can be longer than the LDS-resident kernel takes
     // Segments above kSegMax rows were flagged and left untouched by the kernel (a tile with more than 512 detections: max_det > 512, or
     // a foreign model without a cap): those go through the dense path of obb_merge_detections, one by one.  (synchronises, 4 bytes;
-    // skipped inside a stream capture, where the caller must keep segments within 512 rows)
+    // skipped inside a stream capture, where the caller must keep segments within 512 rows: a longer one replays as "identity order, nothing
+    // kept" -- defined, and visible in the status word of workspace WS_GEOM_E)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return OBB_OK;
     int32_t flagged = 0;
@@ -1268,7 +1433,7 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         int32_t h[2] = {0, (int32_t)n};
         OBB_HIP(ctx, hipMemcpyAsync(segoff, h, sizeof h, hipMemcpyHostToDevice, st));
         OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, thr, order, keep, n_keep, status, 0);
+        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }
@@ -1398,6 +1563,68 @@ int obb_tile_postprocess(obb_ctx *ctx, const float *local_pts, const int32_t *cl
     OBB_REQUIRE(ctx, local_pts && cls && det_tile && rects && gboxes && angle && inside, "obb_tile_postprocess: NULL buffer");
     hipLaunchKernelGGL(k_tile_post, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, local_pts, cls, det_tile, n, rects,
                        margin, strike_cls, gboxes, angle, inside);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_tile_survivors(obb_ctx *ctx, const float *det, const int32_t *count, int32_t B, int32_t max_det, const float *lb, const int32_t *tile_ids,
+                       const int32_t *rects, int32_t margin, int32_t strike_cls, double iou_thr, int32_t *records, int32_t *tile_off, int32_t *n_records,
+                       obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0 && max_det >= 1, "obb_tile_survivors: bad arguments");
+    OBB_REQUIRE(ctx, max_det <= kSegMax, "obb_tile_survivors: max_det %d exceeds the LDS-resident segment merge (%d rows)", max_det, kSegMax);
+    hipStream_t st = (hipStream_t)s;
+    OBB_REQUIRE(ctx, n_records, "obb_tile_survivors: NULL n_records");
+    if (B == 0) { OBB_HIP(ctx, hipMemsetAsync(n_records, 0, sizeof(int32_t), st)); return OBB_OK; }
+    OBB_REQUIRE(ctx, det && count && tile_ids && rects && records && tile_off, "obb_tile_survivors: NULL buffer");
+    const int64_t cap = (int64_t)B * max_det;
+    OBB_REQUIRE(ctx, cap < (1ll << 31), "obb_tile_survivors: B * max_det too large");
+    // scratch: staging rows + merge outputs (grow-only workspace slots of the context)
+    const size_t a_bytes = (size_t)cap * (64 + 8 + 32 + 4 + 4) + 256, b_bytes = (size_t)cap * (4 + 1) + (size_t)B * 12 + 1024;
+    char *wa = (char *)ctx->workspace(WS_SURV_A, a_bytes), *wb = (char *)ctx->workspace(WS_SURV_B, b_bytes);
+    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
+    if (!wa || !wb || !status) return set_error(ctx, OBB_ERR_HIP, "obb_tile_survivors: workspace allocation failed");
+    SurvStage S;
+    S.gb = (double *)wa; S.conf = (double *)(wa + (size_t)cap * 64); S.pts = (float *)(wa + (size_t)cap * 72); S.cls = (int32_t *)(wa + (size_t)cap * 104);
+    S.conf32 = (float *)(wa + (size_t)cap * 108);
+    int32_t *order = (int32_t *)wb;
+    S.lo = (int32_t *)(wb + (size_t)cap * 4); S.hi = S.lo + B;
+    int32_t *nkeep = S.hi + B;
+    uint8_t *keep = (uint8_t *)(nkeep + B + 4);
+    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_tile_stage, dim3((unsigned)B), dim3(256), 0, st, det, count, (int)max_det, lb, tile_ids, rects, (int)margin, (int)strike_cls, S);
+    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)B), dim3(64), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep);
+    if (max_det > kSegWave)  // (tiles with more than 64 survivors: the workgroup-per-segment form; shorter segments return at once)
+        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)B), dim3(1024), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep, status, kSegWave);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nkeep, (int)B, tile_off, n_records);
+    hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)B), dim3(64), 0, st, S, order, keep, tile_off, tile_ids, records);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_select_kept(obb_ctx *ctx, const int32_t *order, const uint8_t *keep, int64_t n, const double *boxes, const int32_t *cls, const double *conf,
+                    const double *angle, double *out_boxes, int32_t *out_cls, double *out_conf, double *out_angle, int32_t *n_out, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0 && n_out, "obb_select_kept: bad arguments");
+    if (n == 0) { OBB_HIP(ctx, hipMemsetAsync(n_out, 0, sizeof(int32_t), (hipStream_t)s)); return OBB_OK; }
+    OBB_REQUIRE(ctx, order && keep && boxes && cls && conf && out_boxes && out_cls && out_conf && (!angle || out_angle), "obb_select_kept: NULL buffer");
+    hipLaunchKernelGGL(k_select_kept, dim3(1), dim3(1024), 0, (hipStream_t)s, order, keep, n, boxes, cls, conf, angle, out_boxes, out_cls, out_conf, out_angle, n_out);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_records_to_dets(obb_ctx *ctx, const int32_t *records, int64_t n, const int32_t *rects, int32_t strike_cls, double *gboxes, int32_t *cls,
+                        double *conf, double *angle, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_records_to_dets: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, records && rects && gboxes && cls && conf && angle, "obb_records_to_dets: NULL buffer");
+    hipLaunchKernelGGL(k_records_to_dets, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, records, n, rects, (int)strike_cls, gboxes, cls, conf, angle);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_gather_compact(obb_ctx *ctx, const int32_t *recv, int32_t world, int32_t capacity, int32_t *out, int32_t *counts, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && world >= 1 && world <= 4096 && capacity >= 1, "obb_gather_compact: bad arguments");
+    OBB_REQUIRE(ctx, recv && out && counts, "obb_gather_compact: NULL buffer");
+    hipLaunchKernelGGL(k_gather_compact, dim3((unsigned)cdiv((int64_t)capacity * 3, 256), (unsigned)world), dim3(256), 0, (hipStream_t)s, recv, (int)world, (int)capacity, out, counts);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

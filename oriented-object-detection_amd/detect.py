@@ -65,13 +65,25 @@ def _dev():
 
 
 class DetSet:
-    """SoA detections resident on the device: boxes f64 [n,8], cls i32 [n], conf f64 [n], angle f64 [n]."""
+    """SoA detections resident on the device: boxes f64 [n,8], cls i32 [n], conf f64 [n], angle f64 [n].
+    `count` (optional device int32[1]): only the first count rows are valid -- the tensors then have capacity rows and the number is read
+    from the device the first time somebody asks for it (len(), to_tuples(), ...), not when the set is produced."""
 
-    def __init__(self, boxes, cls, conf, angle):
-        self.boxes, self.cls, self.conf, self.angle = boxes, cls, conf, angle
+    def __init__(self, boxes, cls, conf, angle, count=None):
+        self._b, self._c, self._f, self._a, self.count, self._n = boxes, cls, conf, angle, count, None
 
     def __len__(self):
-        return int(self.cls.shape[0])
+        if self._n is None:
+            self._n = int(self.count.item()) if self.count is not None else int(self._c.shape[0])
+        return self._n
+
+    def _trimmed(self, t):
+        return t if self.count is None or t.shape[0] == len(self) else t[:len(self)]
+
+    boxes = property(lambda self: self._trimmed(self._b))
+    cls = property(lambda self: self._trimmed(self._c))
+    conf = property(lambda self: self._trimmed(self._f))
+    angle = property(lambda self: self._trimmed(self._a))
 
     @staticmethod
     def empty(device=None):
@@ -132,7 +144,8 @@ def merge_detections_device(ds, iou_threshold=0.5):
     if len(ds) == 0:
         return ds, torch.zeros(0, dtype=torch.int32, device=ds.cls.device)
     order, keep, _ = ops.merge_detections(ds.boxes, ds.cls, ds.conf, iou_threshold)
-    return ds.select(order[keep.bool()]), order
+    b, c, f, a, cnt = ops.select_kept(order, keep, ds.boxes, ds.cls, ds.conf, ds.angle)  # kept rows in merge order; their number stays on the device
+    return DetSet(b, c, f, a, count=cnt), order
 
 
 def merge_detections(detections, iou_threshold=0.5):
@@ -178,16 +191,42 @@ def cross_scale_consensus_filter(dets_by_scale):
 
 
 # ---------------------------------------------------------------- S5
+USE_TILE_SURVIVORS = True  # False: the stand-alone kernels glued by host-side compactions (kept as the A/B reference of the fused path)
+
+
 class TileRecords:
     """Per-tile survivors in the exchange format of the multi-GPU path (48 B/record):
     tile index, class, float32 confidence and the 8 float32 LOCAL corners.  Global float64 coordinates and the strike
-    angle are re-derived exactly at the consumer (records_to_detset), so nothing is lost by shipping float32."""
+    angle are re-derived exactly at the consumer (records_to_detset), so nothing is lost by shipping float32.
+    Two carriers: separate arrays (tile, cls, conf, pts), or the packed int32 [capacity, 12] rows of obb_tile_survivors with their
+    count still on the device (`packed`, `count`): the count is read once, when the length or a column is first needed."""
 
-    def __init__(self, tile, cls, conf, pts):
-        self.tile, self.cls, self.conf, self.pts = tile, cls, conf, pts  # i32[n], i32[n], f32[n], f32[n,8]
+    def __init__(self, tile=None, cls=None, conf=None, pts=None, packed=None, count=None):
+        self._cols = None if tile is None else (tile, cls, conf, pts)  # i32[n], i32[n], f32[n], f32[n,8]
+        self.packed, self.count, self._n = packed, count, None
+
+    @staticmethod
+    def from_packed(packed, count):
+        return TileRecords(packed=packed, count=count)
 
     def __len__(self):
-        return int(self.tile.shape[0])
+        if self._n is None:
+            self._n = int(self._cols[0].shape[0]) if self._cols is not None else int(self.count.item())
+        return self._n
+
+    def _col(self, i):
+        if self._cols is None:
+            self._cols = TileRecords.unpack(self.packed[:len(self)])._cols
+        return self._cols[i]
+
+    tile = property(lambda self: self._col(0))
+    cls = property(lambda self: self._col(1))
+    conf = property(lambda self: self._col(2))
+    pts = property(lambda self: self._col(3))
+
+    @property
+    def device(self):
+        return self.packed.device if self.packed is not None else self._cols[0].device
 
     @staticmethod
     def empty(device):
@@ -196,6 +235,8 @@ class TileRecords:
 
     def pack(self):
         """-> int32 [n,12] (bit-exact container for the all-gather)"""
+        if self.packed is not None:
+            return self.packed[:len(self)]
         n = len(self)
         buf = torch.zeros((n, 12), dtype=torch.int32, device=self.tile.device)
         buf[:, 0], buf[:, 1] = self.tile, self.cls
@@ -230,7 +271,9 @@ def _tile_records(local_pts, cls, conf32, det_tile, rects_dev, cfg, tile_size):
 def records_to_detset(rec, rects_dev, cfg, tile_size):
     """Rebuild global float64 boxes + strike angles from exchange records (exact: float32 local + integer offset)."""
     if len(rec) == 0:
-        return DetSet.empty(rec.tile.device)
+        return DetSet.empty(rec.device)
+    if rec.packed is not None:  # one kernel over the packed rows (no column copies)
+        return DetSet(*ops.records_to_dets(rec.packed, len(rec), rects_dev, cfg.strike_cls))
     gb, ang, _ = ops.tile_postprocess(rec.pts, rec.cls, rec.tile, rects_dev, 0, cfg.strike_cls)
     return DetSet(gb, rec.cls, rec.conf.double(), ang)
 
@@ -240,7 +283,12 @@ def predict_tile_records(model, tiles, rects_dev, tile_ids, lb, cfg, tile_size, 
     letterboxed tiles.  tile_ids int32[B] (index into rects_dev), lb float[B,3] or None.  -> TileRecords."""
     dev = tiles.device
     md = cfg.max_det
-    det, cnt = model.predict_tiles(tiles, conf, cfg.iou_nms, md)
+    fused = USE_TILE_SURVIVORS and md <= 512
+    det, cnt = model.predict_tiles(tiles, conf, cfg.iou_nms, md, zero=not fused)
+    if fused:  # everything up to the exchange records on the device (obb_tile_survivors); the count is read when it is first needed
+        margin = cfg.margin_for(tile_size) if cfg.APPLY_BORDER_FILTER else 0
+        rec, _, n = ops.tile_survivors(det, cnt, lb, tile_ids, rects_dev, margin, cfg.iou_threshold, cfg.strike_cls)
+        return TileRecords.from_packed(rec, n)
     valid = (torch.arange(md, device=dev)[None, :] < cnt[:, None]).reshape(-1)
     rows = torch.nonzero(valid).squeeze(1)  # tile-major, score order inside a tile
     if rows.numel() == 0:
@@ -285,6 +333,8 @@ def detect_symbols_records(image, model, tile_size, overlap, cfg=DEFAULT, conf=N
             parts.append(predict_tile_records(model, tiles, rects_dev, pidx, lb, cfg, tile_size, conf))
     if not parts:
         return TileRecords.empty(dev), rects_dev
+    if len(parts) == 1:
+        return parts[0], rects_dev  # (stays in packed form, count on the device)
     rec = TileRecords(torch.cat([r.tile for r in parts]), torch.cat([r.cls for r in parts]), torch.cat([r.conf for r in parts]),
                       torch.cat([r.pts for r in parts]))
     if len(groups) > 1 and len(rec):  # restore the reference's tile visiting order (stable: keeps score order inside a tile)

@@ -3,8 +3,9 @@
 Tiles are independent through forward / decode / Fast-NMS / border filter / per-tile merge (Detect_OBB.py:216-264 has
 no cross-tile state), so the tile list is sharded across ranks with no data-path collective.  Only the fusion steps
 (:290-291) need every detection of an image: survivors are exchanged once per image as fixed 48-byte records in ONE
-fixed-capacity all-gather (row 0 of every rank's buffer carries its count; KB- to MB-scale, latency-bound, a single
-step, one host read), after which every rank holds the identical, tile-ordered record list and runs the fusion replicated.
+fixed-capacity all-gather (row 0 of every rank's buffer carries its count, written on the device; KB- to MB-scale,
+latency-bound, a single step), compacted by one kernel (obb_gather_compact) whose small count tensor is the step's one host
+read, after which every rank holds the identical, tile-ordered record list and runs the fusion replicated.
 RCCL itself has not been executed yet (no multi-GPU box was available to the builder): the exchange is covered by 2-rank gloo
 tests on CPU and a 2-rank gloo rehearsal on one MI355X.
 """
@@ -24,43 +25,56 @@ def shard_bounds(n_items, rank, world):
 
 def all_gather_records(rec, group=None, capacity=None):
     """Variable-length all-gather of TileRecords in ONE collective: every rank contributes a fixed-capacity int32 [capacity + 1, 12]
-    buffer whose row 0 carries its record count; the `world` counts are then read with one host transfer and the valid rows sliced.
-    Result is ordered by (rank, local order) == tile order for contiguous shards.  `capacity` (records per rank) defaults to the next
-    power of two above this rank's count, agreed through the same collective: a rank whose count exceeds the agreed capacity triggers
-    one second, larger exchange (rare: survivors are a few per tile), so nothing is ever truncated."""
+    buffer whose row 0 carries its record count (written on the device: the local count is never read by the host).  After the
+    collective one kernel (obb_gather_compact) packs the valid rows of all ranks densely, in rank order == tile order for contiguous
+    shards, and leaves the per-rank counts + their total in one small tensor: that tensor is the single host read of the step.
+    `capacity` (records per rank) must be the same on every rank: by default it is sticky per process group -- it starts at 16384 (or
+    `capacity`) and, when some rank's count exceeds it (every rank sees the same counts, so every rank takes this branch), doubles to
+    the next power of two for a second exchange and for all later steps.  Nothing is ever truncated."""
+    from . import ops
     world = dist.get_world_size(group)
     if world == 1:
         return rec
-    dev = rec.tile.device
-    # RCCL ("nccl") exchanges device buffers directly over xGMI; the gloo rehearsal path (CPU tests, single-GPU boxes) stages
-    # through host memory.
-    xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    buf = rec.pack().to(xdev)
-    n = buf.shape[0]
+    dev = torch.device(rec.device)
+    nccl = dist.get_backend(group) == "nccl"
+    packed = rec.packed if rec.packed is not None else rec.pack()          # [rows >= n, 12] on the device
+    n_dev = rec.count if rec.count is not None else torch.tensor([len(rec)], dtype=torch.int32, device=dev)
+    key = id(group) if group is not None else 0
+    cap = int(capacity) if capacity else _CAPACITY.get(key, 16384)
 
     def exchange(cap):
-        send = torch.zeros((cap + 1, 12), dtype=torch.int32, device=xdev)
-        send[0, 0] = n
-        m = min(n, cap)
-        send[1:1 + m] = buf[:m]
-        recv = torch.empty(world * (cap + 1) * 12, dtype=torch.int32, device=xdev)
-        dist.all_gather_into_tensor(recv, send.view(-1), group=group)
-        recv = recv.view(world, cap + 1, 12)
-        return recv, recv[:, 0, 0].tolist()  # the one host read of this step
+        send = torch.empty((cap + 1, 12), dtype=torch.int32, device=dev)
+        send[0, 0:1] = n_dev                                               # device-to-device: no host read of the local count
+        m = min(cap, packed.shape[0])
+        send[1:1 + m] = packed[:m]                                         # rows past the count are never looked at by the receiver
+        if nccl:  # RCCL exchanges the device buffers directly over xGMI
+            recv = torch.empty((world, cap + 1, 12), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+        else:     # gloo rehearsal (CPU tests, single-GPU boxes): staged through host memory
+            recv_h = torch.empty(world * (cap + 1) * 12, dtype=torch.int32)
+            dist.all_gather_into_tensor(recv_h, send.view(-1).cpu(), group=group)
+            recv = recv_h.view(world, cap + 1, 12).to(dev)
+        if dev.type == "cpu":  # host tensors (the 2-rank gloo test on CPU): the same row bookkeeping by plain indexing, no arithmetic involved
+            cs = recv[:, 0, 0].tolist()
+            rows = torch.cat([recv[r, 1:1 + min(c, cap)] for r, c in enumerate(cs)], 0)
+            return rows, cs + [int(rows.shape[0])]
+        rows, counts = ops.gather_compact(recv)
+        return rows, counts.tolist()                                       # the one host read of this step: world counts + the total
 
-    cap = int(capacity) if capacity else _DEFAULT_CAPACITY.get("cap", 1024)
-    recv, counts = exchange(cap)
-    if max(counts) > cap:  # some rank did not fit: every rank sees the same counts, so every rank takes this branch
-        cap = 1 << (max(counts) - 1).bit_length()
-        _DEFAULT_CAPACITY["cap"] = max(_DEFAULT_CAPACITY.get("cap", 1024), cap)  # sticky: the next steps start large enough
-        recv, counts = exchange(cap)
-    if sum(counts) == 0:
+    rows, counts = exchange(cap)
+    if max(counts[:world]) > cap:  # some rank did not fit
+        cap = 1 << (max(counts[:world]) - 1).bit_length()
+        rows, counts = exchange(cap)
+    _CAPACITY[key] = max(_CAPACITY.get(key, 0), cap)
+    total = counts[world]
+    if total == 0:
         return TileRecords.empty(dev)
-    rows = torch.cat([recv[r, 1:1 + c] for r, c in enumerate(counts) if c], 0)
-    return TileRecords.unpack(rows.contiguous().to(dev))
+    out = TileRecords.from_packed(rows, None)
+    out._n = total
+    return out
 
 
-_DEFAULT_CAPACITY = {}
+_CAPACITY = {}  # process group -> sticky capacity (records per rank)
 
 
 def detect_symbols_distributed(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256, group=None):

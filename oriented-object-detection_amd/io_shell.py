@@ -94,8 +94,11 @@ def save_outputs(image_bgr, image_path, output_dir, dets, class_names):
     from PIL import Image
     os.makedirs(output_dir, exist_ok=True)
     name = os.path.basename(image_path)
-    xlsx = os.path.join(output_dir, name.replace(".jpg", ".xlsx").replace(".png", ".xlsx"))
-    jpg = os.path.join(output_dir, name.replace(".jpg", "_detected.jpg").replace(".png", "_detected.jpg"))
+    # .jpg / .png names come out exactly as the reference's str.replace gives them (:299, :322); for the other extensions its loop accepts
+    # (.jpeg / .tif / .tiff, :750) that replace is a no-op and pandas then rejects the ".tif" workbook name -- here the stem is used
+    stem = os.path.splitext(name)[0]
+    xlsx = os.path.join(output_dir, stem + ".xlsx")
+    jpg = os.path.join(output_dir, stem + "_detected.jpg")
     Image.fromarray(draw_detections(image_bgr, dets, class_names)[:, :, ::-1]).save(jpg, quality=95)
     rows = [[class_names.get(d[8], f"Class{d[8]}")] + [float(v) for v in d[:8]] + [float(d[9]), float(d[10])] for d in dets]
     write_xlsx(xlsx, rows)
@@ -103,14 +106,15 @@ def save_outputs(image_bgr, image_path, output_dir, dets, class_names):
 
 
 def main(input_dir="Input", output_dir="Output", models=None, cfg=None):
-    """The script's main loop (Detect_OBB.py:745-755): every .jpg / .png of input_dir through process_image, outputs into output_dir."""
+    """The script's main loop (Detect_OBB.py:745-755): every .jpg / .png / .jpeg / .tif / .tiff of input_dir (the reference's extension
+    tuple, :750; Pillow reads the first page of a TIFF) through process_image, outputs into output_dir."""
     from . import detect as D
     cfg = cfg or D.DEFAULT
     t0 = time.time()
     os.makedirs(output_dir, exist_ok=True)
     done = {}
     for fname in sorted(os.listdir(input_dir)):
-        if not fname.lower().endswith((".jpg", ".png")):
+        if not fname.lower().endswith((".jpg", ".png", ".jpeg", ".tif", ".tiff")):
             continue
         path = os.path.join(input_dir, fname)
         t1 = time.time()

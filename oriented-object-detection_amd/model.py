@@ -125,12 +125,12 @@ class YOLO:
         self.close()
 
     # ------------------------------------------------------------------ batched device API
-    def predict_tiles(self, tiles, conf=0.25, iou=0.7, max_det=300):
+    def predict_tiles(self, tiles, conf=0.25, iou=0.7, max_det=300, zero=True):
         """tiles uint8 [B,h,w,ch] on device, already letterboxed -> (det [B,max_det,7] (x,y,w,h,conf,cls,theta), count [B])"""
         self._ensure_active()
         B, h, w, ch = tiles.shape
         head = ops.forward(tiles)
-        return ops.decode_nms(head, h, w, conf, iou, max_det)
+        return ops.decode_nms(head, h, w, conf, iou, max_det, zero=zero)
 
     # ------------------------------------------------------------------ Ultralytics-shaped API
     def __call__(self, source, conf=0.25, iou=0.7, max_det=300, **kwargs):

@@ -124,6 +124,29 @@ def _tile_postprocess(local_pts: T, cls: T, det_tile: T, rects: T, margin: int, 
           int(strike_cls), _p(gboxes), _p(angle), _p(inside), _stream())
 
 
+@_op("tile_survivors", ("records", "tile_off", "n_records"))
+def _tile_survivors(det: T, count: T, lb: Optional[T], tile_ids: T, rects: T, margin: int, strike_cls: int, iou_thr: float, records: T, tile_off: T,
+                    n_records: T) -> None:
+    _call("obb_tile_survivors", ctx(det.device), _p(det), _p(count), det.shape[0], det.shape[1], _p(lb), _p(tile_ids), _p(rects), int(margin), int(strike_cls),
+          float(iou_thr), _p(records), _p(tile_off), _p(n_records), _stream())
+
+
+@_op("select_kept", ("out_boxes", "out_cls", "out_conf", "out_angle", "n_out"))
+def _select_kept(order: T, keep: T, boxes: T, cls: T, conf: T, angle: T, out_boxes: T, out_cls: T, out_conf: T, out_angle: T, n_out: T) -> None:
+    _call("obb_select_kept", ctx(order.device), _p(order), _p(keep), order.shape[0], _p(boxes), _p(cls), _p(conf), _p(angle), _p(out_boxes), _p(out_cls),
+          _p(out_conf), _p(out_angle), _p(n_out), _stream())
+
+
+@_op("records_to_dets", ("gboxes", "cls", "conf", "angle"))
+def _records_to_dets(records: T, n: int, rects: T, strike_cls: int, gboxes: T, cls: T, conf: T, angle: T) -> None:
+    _call("obb_records_to_dets", ctx(records.device), _p(records), int(n), _p(rects), int(strike_cls), _p(gboxes), _p(cls), _p(conf), _p(angle), _stream())
+
+
+@_op("gather_compact", ("out", "counts"))
+def _gather_compact(recv: T, out: T, counts: T) -> None:
+    _call("obb_gather_compact", ctx(recv.device), _p(recv), recv.shape[0], recv.shape[1] - 1, _p(out), _p(counts), _stream())
+
+
 @_op("gather_tiles", ("out",))
 def _gather_tiles(image: T, rects: T, tile: int, out: T) -> None:
     H, W, Cc = image.shape
@@ -176,6 +199,14 @@ def _probiou_loss(pred: T, target: T, weight: Optional[T], target_scores_sum: fl
 @_op("tile_labels", ("mask", "out"))
 def _tile_labels(labels: T, rects: T, min_fraction: float, mask: T, out: T) -> None:
     _call("obb_tile_labels", ctx(labels.device), _p(labels), labels.shape[0], _p(rects), rects.shape[0], float(min_fraction), _p(mask), _p(out), _stream())
+
+
+@_op("rotated_tal_assign", ("target_labels", "target_bboxes", "target_scores", "fg_mask", "target_gt_idx"))
+def _rotated_tal_assign(pd_scores: T, pd_bboxes: T, anc_points: T, gt_labels: T, gt_bboxes: T, mask_gt: T, topk: int, alpha: float, beta: float,
+                        target_labels: T, target_bboxes: T, target_scores: T, fg_mask: T, target_gt_idx: T) -> None:
+    bs, na, nc = pd_scores.shape
+    _call("obb_rotated_tal_assign", ctx(pd_scores.device), _p(pd_scores), _p(pd_bboxes), _p(anc_points), _p(gt_labels), _p(gt_bboxes), _p(mask_gt), bs, na, nc,
+          gt_bboxes.shape[1], int(topk), float(alpha), float(beta), _p(target_labels), _p(target_bboxes), _p(target_scores), _p(fg_mask), _p(target_gt_idx), _stream())
 
 
 @_op("dfl_loss", ("loss", "grad_pred"))
@@ -278,8 +309,8 @@ def merge_detections(boxes, cls, conf, thr):
     s = _chk(conf, torch.float64, "conf")
     n = b.shape[0]
     order = torch.empty(n, dtype=torch.int32, device=b.device)
-    keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
-    nk = torch.zeros(1, dtype=torch.int32, device=b.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=b.device)  # (every position is written by the library)
+    nk = torch.empty(1, dtype=torch.int32, device=b.device)
     _O.merge_detections(b, c, s, float(thr), order, keep, nk)
     return order, keep, nk
 
@@ -329,6 +360,84 @@ def tile_postprocess(local_pts, cls, det_tile, rects, margin, strike_cls=1):
     ins = torch.empty(n, dtype=torch.uint8, device=lp.device)
     _O.tile_postprocess(lp, c, dt, r, int(margin), int(strike_cls), gb, ang, ins)
     return gb, ang, ins
+
+
+def rotated_tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=10, alpha=0.5, beta=6.0):
+    """RotatedTaskAlignedAssigner.forward -> (target_labels int32[bs,na], target_bboxes f32[bs,na,5], target_scores f32[bs,na,nc], fg_mask bool[bs,na],
+    target_gt_idx int32[bs,na]); inputs as in ultralytics (pd_scores sigmoid probabilities [bs,na,nc], boxes xywhr in pixels, gt_labels [bs,n_max(,1)],
+    mask_gt [bs,n_max(,1)])."""
+    ps = _chk(pd_scores.float().contiguous(), torch.float32, "pd_scores")
+    pb = _chk(pd_bboxes.float().contiguous(), torch.float32, "pd_bboxes")
+    ap = _chk(anc_points.float().contiguous(), torch.float32, "anc_points")
+    bs, na, nc = ps.shape
+    gb = gt_bboxes.float().contiguous()
+    n_max = gb.shape[1]
+    gl = gt_labels.reshape(bs, n_max).to(torch.int32).contiguous()
+    mg = mask_gt.reshape(bs, n_max).to(torch.uint8).contiguous()
+    d = ps.device
+    tl = torch.empty((bs, na), dtype=torch.int32, device=d)
+    tb = torch.empty((bs, na, 5), dtype=torch.float32, device=d)
+    ts = torch.empty((bs, na, nc), dtype=torch.float32, device=d)
+    fg = torch.empty((bs, na), dtype=torch.uint8, device=d)
+    ti = torch.empty((bs, na), dtype=torch.int32, device=d)
+    _O.rotated_tal_assign(ps, pb, ap, gl, gb, mg, int(topk), float(alpha), float(beta), tl, tb, ts, fg, ti)
+    return tl, tb, ts, fg.bool(), ti
+
+
+def tile_survivors(det, count, lb, tile_ids, rects, margin, iou_thr, strike_cls=1):
+    """det float32[B, max_det, 7] + count int32[B] (decode_nms) -> (records int32[B * max_det, 12] (capacity), tile_off int32[B + 1],
+    n_records int32[1]), all on the device: result construction, per-detection body (border filter `margin`), per-tile merge at `iou_thr`
+    and compaction into exchange records in tile order, with no host-visible count in between."""
+    d = _chk(det, torch.float32, "det")
+    c = _chk(count, torch.int32, "count")
+    ti = _chk(tile_ids, torch.int32, "tile_ids")
+    r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
+    if lb is not None:
+        lb = _chk(lb, torch.float32, "lb").reshape(-1, 3)
+    B, md = d.shape[0], d.shape[1]
+    rec = torch.empty((B * md, 12), dtype=torch.int32, device=d.device)
+    off = torch.empty(B + 1, dtype=torch.int32, device=d.device)
+    n = torch.empty(1, dtype=torch.int32, device=d.device)
+    _O.tile_survivors(d, c, lb, ti, r, int(margin), int(strike_cls), float(iou_thr), rec, off, n)
+    return rec, off, n
+
+
+def select_kept(order, keep, boxes, cls, conf, angle):
+    """rows order[i] of the sorted positions i with keep[i], in that order -> (boxes, cls, conf, angle) of capacity n and n_out int32[1] (device)"""
+    n = order.shape[0]
+    ob = torch.empty((n, 8), dtype=torch.float64, device=order.device)
+    oc = torch.empty(n, dtype=torch.int32, device=order.device)
+    of = torch.empty(n, dtype=torch.float64, device=order.device)
+    oa = torch.empty(n, dtype=torch.float64, device=order.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=order.device)
+    _O.select_kept(_chk(order, torch.int32, "order"), _chk(keep, torch.uint8, "keep"), _chk(boxes, torch.float64, "boxes"), _chk(cls, torch.int32, "cls"),
+                   _chk(conf, torch.float64, "conf"), _chk(angle, torch.float64, "angle"), ob, oc, of, oa, cnt)
+    return ob, oc, of, oa, cnt
+
+
+def records_to_dets(records, n, rects, strike_cls=1):
+    """the first n rows of packed records int32[*, 12] -> (global boxes float64[n, 8], cls int32[n], conf float64[n], angle float64[n])"""
+    rec = _chk(records, torch.int32, "records")
+    r = _chk(rects, torch.int32, "rects").reshape(-1, 4)
+    n = int(n)
+    gb = torch.empty((n, 8), dtype=torch.float64, device=rec.device)
+    c = torch.empty(n, dtype=torch.int32, device=rec.device)
+    f = torch.empty(n, dtype=torch.float64, device=rec.device)
+    a = torch.empty(n, dtype=torch.float64, device=rec.device)
+    if n:
+        _O.records_to_dets(rec, n, r, int(strike_cls), gb, c, f, a)
+    return gb, c, f, a
+
+
+def gather_compact(recv):
+    """recv int32[world, capacity + 1, 12] (all_gather of fixed-capacity record blocks, count in [w, 0, 0]) -> (rows int32[world * capacity, 12]
+    dense in rank order, counts int32[world + 1]: the counts as sent, then the number of rows written)"""
+    r = _chk(recv, torch.int32, "recv")
+    world, cap = r.shape[0], r.shape[1] - 1
+    out = torch.empty((world * cap, 12), dtype=torch.int32, device=r.device)
+    counts = torch.empty(world + 1, dtype=torch.int32, device=r.device)
+    _O.gather_compact(r, out, counts)
+    return out, counts
 
 
 PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016, "f32": 32, "fp32": 32}
@@ -431,13 +540,14 @@ def decode(head, h, w):
     return pred
 
 
-def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False):
+def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False, zero=True):
     """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B]).  full=True runs the reference form (decode
-    every anchor first) that the candidate-first default must reproduce bit for bit."""
+    every anchor first) that the candidate-first default must reproduce bit for bit.  zero=False leaves the rows past count[b]
+    uninitialised (no fill launch: what the device-side consumers, which only look at rows below the count, ask for)."""
     hd = _padded_head(_chk(head, torch.float32, "head"))
     B = hd.shape[0]
-    det = torch.zeros((B, max_det, 7), dtype=torch.float32, device=hd.device)
-    count = torch.zeros(B, dtype=torch.int32, device=hd.device)
+    det = (torch.zeros if zero or not B else torch.empty)((B, max_det, 7), dtype=torch.float32, device=hd.device)
+    count = (torch.zeros if zero or not B else torch.empty)(B, dtype=torch.int32, device=hd.device)
     if B:
         (_O.decode_nms_full if full else _O.decode_nms)(hd, h, w, float(conf), float(iou), int(max_det), det, count)
     return det, count

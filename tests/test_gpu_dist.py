@@ -1,0 +1,55 @@
+"""N > 1 path end to end on the GPU box: two ranks (gloo rendezvous on 127.0.0.1, both on the one card of the box -- RCCL needs one GPU per
+rank, which the 1-GPU box does not have) run process_image_distributed on the same image: sharded tile lists, ONE fixed-capacity
+record exchange per scale with the counts kept on the device, device-side compaction, replicated fusion.  Every rank must end with
+exactly the detections the single-process process_image_device produces."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["OBB_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OBB_ROOT"], "tests"))
+    torch.cuda.set_device(0)
+    import oriented_object_detection_amd
+    from oriented_object_detection_amd import detect as D, dist as DD
+    from oriented_object_detection_amd.model import YOLO
+    from oracle.yolo11_obb import Yolo11OBB
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    img = torch.as_tensor(np.random.default_rng(9).integers(0, 256, (500, 640, 3), dtype=np.uint8)).cuda()
+    models = [YOLO(Yolo11OBB("n", nc=12, ch=3, seed=1), imgsz=128), YOLO(Yolo11OBB("n", nc=12, ch=3, seed=0), imgsz=416)]
+    ok = True
+    for capacity in (None, 8):  # 8: smaller than a shard's survivor count -> the second, larger exchange
+        if capacity:
+            DD._CAPACITY.clear(); DD._CAPACITY[0] = capacity
+        got = DD.process_image_distributed(img, models).to_tuples()
+        exp = D.process_image_device(img, models)["merged_for_pr"].to_tuples()
+        ok = ok and len(exp) > 3 and got == exp
+    flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 3)
+''')
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_process_image_distributed_on_one_card(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, OBB_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

@@ -49,10 +49,11 @@ def test_fp32_layer_taps(ood, nets):
     x = _tiles(1, 2, 416, 416)
     taps = {}
     net.forward_raw(x, "fp32", taps)
-    ops.model_load(net.to_blob(), precision="f32")
+    ops.model_load(net.to_blob(), precision="f32", tail=False, upfold=False, sppf_fuse=False, stem=False)  # one generic kernel per layer: every activation exists
     plan = ops.debug_plan(416, 416)
     assert all(l.startswith(("conv32 ", "dwconv ", "pool ", "upsample ", "attn ", "total_macs")) for l in plan), plan
     assert sum(l.startswith("conv32 ") for l in plan) == 96 - 7  # every dense conv of the blob (7 records are depthwise)
+    assert not any(" tail" in l and " tail0 " not in l for l in plan if l.startswith("conv32 ")) and not any(" vcat1" in l for l in plan)
     ops.forward(torch.as_tensor(x).cuda())
     torch.cuda.synchronize()
     for name in TAPS:
@@ -70,6 +71,38 @@ def test_fp32_layer_taps(ood, nets):
         scale = float(exp.abs().mean())
         print(name, "max", float(d.max()), "mean", float(d.mean()), "scale", scale, flush=True)
         assert float(d.max()) < 1e-3 and float(d.mean()) < 2e-5, name  # measured: mean 1e-7 (model.0) .. 5e-6 (head), max <= 1e-4
+
+
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (64, 96, 3)])
+def test_fp32_fused_forms_are_bit_identical(ood, nets, h, w, B):
+    """The default fp32 plan (trailing 1x1 convs fused behind their producers, Upsample + Concat read in place, merged sibling convs, the
+    three SPPF pools in one launch) against the one-kernel-per-layer plan: every fused form keeps the k order of the layer it replaces
+    (the exact-f32 MFMA is a k-ordered fma chain) and max pooling is exact, so the heads must agree BIT FOR BIT."""
+    ops, net = ood.ops, nets[416]
+    x = torch.as_tensor(_tiles(3 + h, B, h, w)).cuda()
+    ops.model_load(net.to_blob(), precision="f32", tail=False, upfold=False, sppf_fuse=False, stem=False)
+    plain = ops.forward(x).cpu()
+    x0_plain = ops.debug_activation("model.0", B, h, w).cpu()
+    ops.model_load(net.to_blob(), precision="f32", stem=False)
+    plan = ops.debug_plan(h, w)
+    assert any(" tail64 " in l for l in plan) and any(" vcat1 " in l for l in plan) and any("|" in l for l in plan) and any("sppf" in l for l in plan), plan
+    fused = ops.forward(x).cpu()
+    assert torch.equal(fused[..., :77], plain[..., :77]), float((fused - plain)[..., :77].abs().max())
+    # two forms that sum in another order than what they replace: close, not identical
+    # (a) the MFMA attention core vs the scalar one
+    ops.model_load(net.to_blob(), precision="f32", attn_mfma=False, stem=False)
+    scalar = ops.forward(x).cpu()
+    d = (scalar - fused)[..., :77].abs()
+    print(h, w, "attention mfma vs scalar: max", float(d.max()), "mean", float(d.mean()))
+    assert float(d.max()) < 5e-4 and float(d.mean()) < 1e-5
+    # (b) the row-stripe input layer (k dense over the 27 taps) vs the generic kernel (4-channel chunks per tap)
+    ops.model_load(net.to_blob(), precision="f32")
+    assert any(l.startswith("stem32 ") for l in ops.debug_plan(h, w))
+    full = ops.forward(x).cpu()
+    x0 = ops.debug_activation("model.0", B, h, w).cpu()
+    d0, d = (x0 - x0_plain).abs(), (full - fused)[..., :77].abs()
+    print(h, w, "stem stripes vs generic: model.0 max", float(d0.max()), "head max", float(d.max()), "mean", float(d.mean()))
+    assert float(d0.max()) < 2e-6 * max(1.0, float(x0_plain.abs().max())) and float(d.max()) < 5e-4 and float(d.mean()) < 3e-5
 
 
 @pytest.mark.parametrize("h,w,B,ch", [(416, 416, 3, 3), (128, 128, 5, 3), (416, 288, 2, 3), (192, 416, 2, 3), (64, 96, 3, 3), (416, 416, 2, 4)])
@@ -96,14 +129,17 @@ def test_fp32_head_matches_fp32_oracle(ood, nets, h, w, B, ch):
     assert torch.equal(again, head) and torch.equal(one[0], head[1])
 
 
-def _same_dets(got, exp, conf_tol, px_tol, tag=""):
+def _same_dets(got, exp, conf_tol, px_tol, tag="", max_subst=0):
     """identical count; one-to-one correspondence (same class, every corner within px_tol, confidence within conf_tol); identical ORDER
     except between detections whose confidences are closer than 2 * conf_tol (the lists are confidence-sorted: two fp32 evaluations may
-    legitimately swap near-ties)"""
+    legitimately swap near-ties).  max_subst > 0 additionally tolerates that many SUBSTITUTIONS between NMS rivals in a near-tie: the two
+    evaluations kept different members of a pair of overlapping same-class candidates (polygon IoU >= 0.3) whose confidences differ by
+    less than 2 * conf_tol -- which of the two survives the NMS is decided by the last bits of their scores."""
     assert len(got) == len(exp), (len(got), len(exp))
     used, pos = set(), []
     dc = dp = da = 0.0
-    for g in got:
+    subst = []
+    for gi, g in enumerate(got):
         best, bj = None, -1
         for j, e in enumerate(exp):
             if j in used or e[8] != g[8]:
@@ -111,17 +147,30 @@ def _same_dets(got, exp, conf_tol, px_tol, tag=""):
             d = max(abs(a - b) for a, b in zip(g[:8], e[:8]))
             if best is None or d < best:
                 best, bj = d, j
-        assert bj >= 0 and best <= px_tol, (g, best)
+        assert bj >= 0, g
+        if best > px_tol:
+            subst.append(gi)
+            pos.append(None)
+            continue
         used.add(bj)
         pos.append(bj)
         dc, dp, da = max(dc, abs(g[9] - exp[bj][9])), max(dp, best), max(da, abs(g[10] - exp[bj][10]))
+    assert len(subst) <= max_subst, ("unmatched detections", [(got[i], ) for i in subst][:3])
+    for gi in subst:  # each must be the NMS rival of a still unmatched reference detection
+        g = got[gi]
+        cand = [(og.compute_polygon_iou(list(g[:8]), list(e[:8])), j) for j, e in enumerate(exp) if j not in used and e[8] == g[8] and abs(e[9] - g[9]) <= 2 * conf_tol]
+        assert cand and max(cand)[0] >= 0.3, ("not a near-tie between NMS rivals", g, cand)
+        j = max(cand)[1]
+        used.add(j)
+        pos[gi] = j
+        print(f"{tag}: near-tie substitution: device kept conf {g[9]:.6f}, reference kept conf {exp[j][9]:.6f}, IoU of the two {max(cand)[0]:.3f}")
     swaps = 0
     for i, j in enumerate(pos):
         if i != j:
             swaps += 1
             assert abs(exp[i][9] - exp[j][9]) <= 2 * conf_tol, ("order differs beyond a near-tie", i, j, exp[i][9], exp[j][9])
-    print(f"{tag}: {len(got)} detections, identical count / classes; {swaps} positions permuted among near-ties; max |d conf| {dc:.2e}, "
-          f"max |d corner| {dp:.2e} px, max |d angle| {da:.2e} deg")
+    print(f"{tag}: {len(got)} detections, identical count / classes; {swaps} positions permuted among near-ties; {len(subst)} near-tie substitutions; "
+          f"max |d conf| {dc:.2e}, max |d corner| {dp:.2e} px, max |d angle| {da:.2e} deg")
     assert dc <= conf_tol and da <= 0.1
 
 
@@ -146,6 +195,44 @@ def test_fp32_process_image_dual_scale_end_to_end(ood, nets):
     got = ood.detect.process_image(img, None, [m128, m416])
     assert sum(len(v) for v in exp_by_scale.values()) > 20 and len(exp) > 3
     _same_dets(got, exp, 2e-4, 0.1, "fp32 dual-scale process_image 500x640")
+
+
+def test_fp32_four_channel_end_to_end_no_injection(ood):
+    """BASELINE configs[3] on one GPU with NO head injection: a 3-channel BGR image, every crop gets its DT-edge channel on the device
+    (build_multich) and goes through the device's own fp32 forward; the oracle runs its own fp32 forward on the same 4-channel crops
+    (the DT-edge builder has its own parity tests, tests/test_gpu_dtedge.py: on this image its channel differs from the numpy
+    restatement by at most 1 grey level at a few pixels, which is enough to flip a near-tie of the NMS -- so the crops, not the heads,
+    are shared here).  Same bounds as the 3-channel comparisons above; the all-oracle run is compared as a detection set."""
+    net = Yolo11OBB("n", nc=12, ch=4, seed=2)
+    model = ood.model.YOLO(net, imgsz=416, precision="f32")
+    assert model.ch == 4
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (600, 740, 3), dtype=np.uint8)
+    img[100:130, 50:600] = 15
+    img[200:520, 300:330] = (240, 10, 10)
+    got = ood.detect.detect_symbols(img, model, 416, 100)  # 4 tiles: one full, three partial (letterboxed after the channel is built)
+    exp = opl.detect_symbols(img, opl.OracleModel(net, 416, "fp32", multich_fn=lambda crop: ood.detect.build_multich(crop, 4)), 416, 100)
+    assert len(exp) > 5
+    _same_dets(got, exp, 2e-4, 0.1, "fp32 4-channel detect_symbols 600x740", max_subst=2)
+    exp_all = opl.detect_symbols(img, opl.OracleModel(net, 416, "fp32"), 416, 100)  # channel built by the numpy restatement as well
+    pairs, ug, ue = _match_sets(got, exp_all)
+    print(f"4-channel, oracle-built channel: {len(got)} vs {len(exp_all)} detections, matched {len(pairs)}, unmatched {ug}/{ue}")
+    assert 2.0 * len(pairs) / (len(got) + len(exp_all)) >= 0.95
+
+
+def test_fp32_process_image_on_the_real_sample_file_no_injection(ood, nets, tmp_path):
+    """BASELINE configs[0] with nothing injected: process_image(path) on the reference's own Input/Test1.png (9 + 90 tiles, dual scale) in
+    fp32 mode against the CPU pipeline running its own fp32 forwards."""
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "input", "Test1.png")
+    img = ood.detect.imread_bgr(path)
+    m128 = ood.model.YOLO(nets[128], imgsz=128, precision="f32")
+    m416 = ood.model.YOLO(nets[416], imgsz=416, precision="f32")
+    exp, by_scale = opl.process_image(img, [opl.OracleModel(nets[128], 128, "fp32"), opl.OracleModel(nets[416], 416, "fp32")])
+    got = ood.detect.process_image(path, str(tmp_path), [m128, m416])
+    assert len(exp) > 3
+    _same_dets(got, exp, 2e-4, 0.1, "fp32 process_image Test1.png", max_subst=2)
 
 
 def _match_sets(got, exp, iou_min=0.5):
@@ -186,3 +273,14 @@ def test_16bit_detection_set_agreement_with_fp32_reference(ood, nets, precision,
           f"IoU of matched pairs mean {np.mean(ious):.4f} min {np.min(ious):.3f}")
     assert len(exp) > 3 and frac >= min_frac, frac
     assert dconf <= max_conf_d and np.mean(ious) >= min_mean_iou, (dconf, np.mean(ious))
+    # the same agreement split by distance from the confidence thresholds the pipeline applies to a detection (0.25: predictor + consensus
+    # low bound, 0.70: consensus high bound, Detect_OBB.py:83, 349-351): a reference detection whose fp32 confidence is at least 0.05 away
+    # from both cannot be flipped by the 16-bit confidence error itself -- what remains unmatched there was decided by a NEIGHBOUR's flip
+    # (NMS / merge / consensus partner)
+    matched_exp = {j for _, j, _ in pairs}
+    safe = [j for j, e in enumerate(exp) if min(abs(e[9] - 0.25), abs(e[9] - 0.70)) >= 0.05]
+    near = [j for j in range(len(exp)) if j not in set(safe)]
+    f_safe = sum(j in matched_exp for j in safe) / max(1, len(safe))
+    f_near = sum(j in matched_exp for j in near) / max(1, len(near))
+    print(f"{precision}: reference detections >= 0.05 from 0.25 / 0.70: {len(safe)}, matched {f_safe:.4f}; within 0.05: {len(near)}, matched {f_near:.4f}")
+    assert f_safe >= (0.97 if precision == "f16" else 0.70), f_safe

@@ -187,3 +187,86 @@ def test_process_image_on_the_real_sample_file(ood, nets, tmp_path):
     os.symlink(path, tmp_path / "in" / "Test1.png")
     done = io_shell.main(str(tmp_path / "in"), str(tmp_path / "out"), [nets["m128"], nets["m416"]])
     assert len(done) == 1 and os.path.exists(tmp_path / "out" / "Test1.xlsx") and os.path.exists(tmp_path / "out" / "Test1_detected.jpg")
+
+
+# ---------------------------------------------------------------------------------------------- device-side compaction (no torch glue)
+def _records_equal(a, b):
+    return len(a) == len(b) and torch.equal(a.tile, b.tile) and torch.equal(a.cls, b.cls) and torch.equal(a.conf, b.conf) and torch.equal(a.pts, b.pts)
+
+
+@pytest.mark.parametrize("conf,md,lbox", [(0.25, 300, False), (0.02, 300, True), (0.25, 40, False), (0.001, 300, False), (0.9999, 300, False)])
+def test_tile_survivors_equals_the_glued_kernels(ood, nets, conf, md, lbox):
+    """obb_tile_survivors (result construction + per-detection body + per-tile merge + compaction, counts kept on the device) against
+    the stand-alone kernels glued by host-side compactions (obb_results -> obb_tile_postprocess -> obb_merge_segments): the same
+    records, bit for bit, in the same order -- dense tiles (conf 0.001: saturated at max_det), sparse and empty ones, with and
+    without a letterbox, max_det below the candidate count."""
+    D, ops = ood.detect, ood.ops
+    m = nets["m416"]
+    rng = np.random.default_rng(5)
+    B = 9
+    tiles = torch.as_tensor(rng.integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()
+    tiles[3] = 0  # a tile without candidates at the usual thresholds
+    rects = np.array([[(t % 4) * 316, (t // 4) * 316, (t % 4) * 316 + 416, (t // 4) * 316 + 416] for t in range(12)], np.int32)
+    rects_dev = torch.as_tensor(rects).cuda()
+    tile_ids = torch.tensor([0, 2, 3, 5, 6, 7, 9, 10, 11], dtype=torch.int32).cuda()
+    lb = torch.tensor([[0.8, 3.0, 11.0]] * B, dtype=torch.float32).cuda() if lbox else None
+    cfg = D.Config(max_det=md)
+    outs = []
+    for fused in (False, True):
+        D.USE_TILE_SURVIVORS = fused
+        try:
+            outs.append(D.predict_tile_records(m, tiles, rects_dev, tile_ids, lb, cfg, 416, conf))
+        finally:
+            D.USE_TILE_SURVIVORS = True
+    glue, fus = outs
+    assert fus.packed is not None and glue.packed is None
+    assert _records_equal(glue, fus), (len(glue), len(fus))
+    if conf == 0.9999:
+        assert len(fus) == 0
+    elif conf <= 0.25:
+        assert len(fus) > 0
+    # the consumer side: packed rows -> detections == column form -> detections
+    a, b = D.records_to_detset(fus, rects_dev, cfg, 416), D.records_to_detset(glue, rects_dev, cfg, 416)
+    assert len(a) == len(b)
+    if len(a):
+        assert torch.equal(a.boxes, b.boxes) and torch.equal(a.cls, b.cls) and torch.equal(a.conf, b.conf) and torch.equal(a.angle, b.angle)
+
+
+def test_select_kept_and_lazy_counts(ood, ref_vectors):
+    """merge_detections_device returns the kept rows through obb_select_kept (ordered compaction, count on the device): identical to
+    indexing with the boolean mask on the host side, for the reference-generated merge cases and a 20 000-row set"""
+    D, ops = ood.detect, ood.ops
+    rv = ref_vectors
+    rng = np.random.default_rng(11)
+    cases = [(rv["merge3_boxes"], rv["merge3_cls"], rv["merge3_conf"], float(rv["merge3_thr"]))]
+    n = 20000
+    ctr = rng.uniform(0, 4000, (n, 2)); wh = rng.uniform(8, 60, (n, 2)); th = rng.uniform(0, np.pi, n)
+    c, s = np.cos(th), np.sin(th)
+    corners = np.stack([ctr + np.stack([sx * wh[:, 0] / 2 * c - sy * wh[:, 1] / 2 * s, sx * wh[:, 0] / 2 * s + sy * wh[:, 1] / 2 * c], 1)
+                        for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1))], 1).reshape(n, 8)
+    cases.append((corners, rng.integers(0, 3, n), np.round(rng.uniform(0.25, 1, n), 2), 0.4))
+    for boxes, cls, conf, thr in cases:
+        ds = D.DetSet(torch.as_tensor(np.ascontiguousarray(boxes, np.float64)).cuda(), torch.as_tensor(np.asarray(cls, np.int32)).cuda(),
+                      torch.as_tensor(np.asarray(conf, np.float64)).cuda(), torch.zeros(len(cls), dtype=torch.float64).cuda())
+        order, keep, nk = ops.merge_detections(ds.boxes, ds.cls, ds.conf, thr)
+        exp = ds.select(order[keep.bool()])
+        got, order2 = D.merge_detections_device(ds, thr)
+        assert got.count is not None and got._n is None  # nothing read yet
+        assert len(got) == int(nk.item()) == len(exp) and torch.equal(order2, order)
+        assert torch.equal(got.boxes, exp.boxes) and torch.equal(got.cls, exp.cls) and torch.equal(got.conf, exp.conf) and torch.equal(got.angle, exp.angle)
+
+
+def test_gather_compact(ood):
+    """the fixed-capacity all-gather buffer of 5 'ranks' (one empty, one over capacity) -> dense rows in rank order + counts"""
+    ops = ood.ops
+    rng = np.random.default_rng(2)
+    world, cap = 5, 37
+    counts = [12, 0, 37, 60, 5]  # rank 3 sent a count above the capacity: its first `cap` rows arrive, the count tells the caller to repeat
+    recv = torch.as_tensor(rng.integers(-2**31, 2**31 - 1, (world, cap + 1, 12), dtype=np.int64).astype(np.int32))
+    for r, c in enumerate(counts):
+        recv[r, 0, 0] = c
+    rows, cnt = ops.gather_compact(recv.cuda())
+    cnt = cnt.cpu().tolist()
+    exp = torch.cat([recv[r, 1:1 + min(c, cap)] for r, c in enumerate(counts)], 0)
+    assert cnt[:world] == counts and cnt[world] == exp.shape[0]
+    assert torch.equal(rows[:cnt[world]].cpu(), exp)

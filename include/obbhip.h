@@ -168,6 +168,16 @@ int obb_rotated_tal_assign(obb_ctx *ctx, const float *pd_scores, const float *pd
                            float alpha, float beta, int32_t *target_labels, float *target_bboxes, float *target_scores, uint8_t *fg_mask,
                            int32_t *target_gt_idx, obb_stream_t s);
 
+/* ------------------------------------------------------------------ training step, slice 3 */
+/* Backward of a stride-1 convolution with `same` padding (k = 1 or 3), bf16 NHWC tensors, fp32 accumulation (Train_OBB.py:796-841: bf16
+ * autocast over fp32 master weights).  dgrad: dy bf16[B][H][W][cout] (device), w fp32[cout][cin][k][k] (HOST: repacked per call into
+ * the MFMA fragment order of the forward kernel) -> dx bf16[B][H][W][cin].  wgrad: x bf16[B][H][W][cin], dy -> dw fp32[cout][cin][k][k]
+ * (device), cin and cout multiples of 64; deterministic (fixed summation order). */
+int obb_conv_dgrad_bf16(obb_ctx *ctx, const uint16_t *dy, const float *w_oihw_host, int32_t B, int32_t H, int32_t W, int32_t cin,
+                        int32_t cout, int32_t ks, uint16_t *dx, obb_stream_t s);
+int obb_conv_wgrad_bf16(obb_ctx *ctx, const uint16_t *x, const uint16_t *dy, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                        int32_t ks, float *dw, obb_stream_t s);
+
 /* ------------------------------------------------------------------ S1: model(...) -> results[0].obb  (Detect_OBB.py:26,81-83,228-231) */
 /* Weight blob ("OBBW" format, produced by the Python side from BN-folded conv weights) for a
  * YOLO11-OBB graph (ultralytics==8.3.196 yolo11-obb.yaml).  Host pointer.  (synchronises) */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "obb_records_to_dets": [_V, _V, C.c_int64, _V, C.c_int32, _V, _V, _V, _V, _V],
     "obb_gather_compact": [_V, _V, C.c_int32, C.c_int32, _V, _V, _V],
     "obb_rotated_tal_assign": [_V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _V, _V, _V, _V, _V, _V],
+    "obb_conv_dgrad_bf16": [_V, _V, c_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
+    "obb_conv_wgrad_bf16": [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
     "obb_gather_tiles": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, C.c_int32, C.c_int32, _V, _V],
     "obb_letterbox": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V,
                       C.c_int32, C.c_int32, _V],

@@ -1154,6 +1154,7 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
             if (L.res.cpb > 0) { P.res = (const bf16_t *)L.res.p + (int64_t)(L.res.co / (8 * L.res.cpb)) * L.res.ps; P.res_co = 0; }
         }
     }
+    if (!L.lut) return hipErrorInvalidValue;  // also the sink of the unconditional stores (lut + 512 B .. + 1.5 KiB): never NULL
     P.wpk = L.wpk; P.bias = L.bias; P.lut = L.lut;
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout;
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;

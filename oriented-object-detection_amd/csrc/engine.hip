@@ -334,7 +334,7 @@ struct Builder {
             Conv32Launch &L = op.c32;
             const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8, op.vin);
             L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act; L.in_u8 = in_u8; L.flip_bgr = (in_u8 && M.ch == 3);
-            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM;
+            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM; L.NI = t.NI;
             L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
             L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
             if (op.vin && (P.bufs[in.buf].va_C % t.CK || t.WC != 4)) { err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the virtual concat in fp32 mode", name.c_str()); return; }
@@ -351,7 +351,7 @@ struct Builder {
                     err = set_error(ctx, OBB_ERR_STATE, "fused 1x1 %s: no fp32 kernel for this pair", tail_name);
                     return;
                 }
-                const Conv32Tiling t2{1, 1, r->c2, 1, 1};
+                const Conv32Tiling t2{1, 1, r->c2, 1, 1, 1};
                 L.tail_w = upload(pack_conv32_weights(r2->w, r2->c2, r->c2, 1, t2, nullptr, false));
                 std::vector<float> b2(((size_t)r2->c2 + 63) / 64 * 64 + 64, 0.f);
                 for (int c = 0; c < r2->c2; ++c) b2[c] = r2->b[c];
@@ -1292,8 +1292,8 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
         switch (op.type) {
             case OP_CONV32: {
                 const Conv32Launch &L = op.c32;
-                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d CK%d WC%d MFM%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
-                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.CK, L.WC, L.MFM, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
+                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d NI%d CK%d WC%d MFM%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
+                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.NI, L.CK, L.WC, L.MFM, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
                 break;
             }
             case OP_CONV: {

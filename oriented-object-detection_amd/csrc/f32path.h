@@ -37,10 +37,11 @@ struct Conv32Launch {
     // tiling (plan_conv32): output tile TH x TW (<= 16 * (8 / WC) * MFM pixels), CK input channels per LDS stage, WC of the workgroup's 8
     // waves along cout (16 couts each), the other 8 / WC along the pixel fragments, MFM fragments of 16 pixels per wave
     int TH = 1, TW = 208, CK = 16, WC = 4, MFM = 7;
+    int NI = 1;  // > 1: one tile = NI whole images of a small map (TH x TW = the map; the 8 x 8 / 4 x 4 levels of the 128-px scale)
     int tiles_y = 1, tiles_x = 1;
 };
 
-struct Conv32Tiling { int TH, TW, CK, WC, MFM; };
+struct Conv32Tiling { int TH, TW, CK, WC, MFM, NI; };
 Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat = false);  // vcat: the input is a virtual [upsample | skip] concat
 // true if the 1x1 conv (cout1 -> cout2) can run as the fused tail of a layer tiled as `t`
 bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2);

@@ -38,6 +38,7 @@ struct C32Params {
     const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
+    int NI, B;  // NI > 1: a tile = NI whole images of a small map (TH x TW = the map), B images in all
     float inv_twin, inv_tw;
     unsigned in_span_bytes;  // buffer-descriptor range of one image's input slice (its check returns zeros past the end)
 };
@@ -76,24 +77,31 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     const int PST = P.CK * 4 + 16;  // bytes per staged pixel (+16 B spreads consecutive pixels over the banks)
     const int cpk = P.CK >> 2;
     const int nq = (KS == 3 ? 9 : 1) * cpk;
-    const int in_px = THin * TWin;
-    const int tx_i = t % P.tiles_x, r_ = t / P.tiles_x, ty_i = r_ % P.tiles_y, b = r_ / P.tiles_y;
+    const int in_px1 = THin * TWin;          // staged pixels of one image
+    const int in_px = in_px1 * P.NI;
+    const int tx_i = t % P.tiles_x, r_ = t / P.tiles_x, ty_i = r_ % P.tiles_y;
+    const int b = P.NI > 1 ? t * P.NI : r_ / P.tiles_y;  // (first) image of this tile
+    const int nimg = P.NI > 1 ? min(P.NI, P.B - b) : 1;
     const int oy0 = ty_i * P.TH, ox0 = tx_i * P.TW;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     // valid pixels of this tile (edge tiles are clipped): fragments past them are not computed
     const int vh = min(P.TH, P.Hout - oy0), vw = min(P.TW, P.Wout - ox0);
-    const int npix = P.TH * P.TW;
-    const int nfrag = ((vh == P.TH ? npix : vh * P.TW) + 15) >> 4;  // whole rows: a clipped tile loses its trailing rows (1-D: TH = 1, all kept)
+    const int tpi = P.TH * P.TW;             // output pixels of one image's part of the tile
+    const int npix = tpi * P.NI;
+    const int nfrag = ((P.NI > 1 ? nimg * tpi : (vh == P.TH ? tpi : vh * P.TW)) + 15) >> 4;  // whole rows: a clipped tile loses its trailing rows (1-D: TH = 1, all kept)
     const int nfrag1 = (P.TH == 1) ? ((vw + 15) >> 4) : nfrag;
     const bool lastv = wp + WP * (MFM - 1) < nfrag1;  // (wave-uniform) the last fragment of this wave exists
+    const float inv_tpi = 1.0f / (float)tpi, inv_in1 = 1.0f / (float)in_px1;
 
     int pixbase[MFM];
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) {
         const int p = (wp + WP * mf) * 16 + pl;
-        const int ty = (int)(((float)p + 0.5f) * P.inv_tw);
-        const int tx = p - ty * P.TW;
-        pixbase[mf] = p < npix ? ((ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
+        const int il = P.NI > 1 ? (int)(((float)p + 0.5f) * inv_tpi) : 0;
+        const int q = p - il * tpi;
+        const int ty = (int)(((float)q + 0.5f) * P.inv_tw);
+        const int tx = q - ty * P.TW;
+        pixbase[mf] = p < npix ? (il * in_px1 + (ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
     }
     const int F = cb * WC + wc;  // cout fragment of this wave
     // weights of (cout block cb, stage): WC * kst pieces of 1 KiB, contiguous (pack_conv32_weights); LDS image behind the activation tile
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     // staging plan: this thread moves the 16-B chunks idx = tid + k * NT of the [in_px][CK] tile.  Activations come through buffer
     // loads (descriptor in SGPRs, one 32-bit byte offset per chunk): an offset past the descriptor's range reads zeros, which is how
     // the zero padding is written
-    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (VCAT ? 4 : 7) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
+    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (VCAT ? 4 : 6) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
     constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4)
     constexpr unsigned NOPIX = 0xffffffffu;
     const int nchunk = in_px * cpk;
@@ -124,9 +132,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             int pix, c;
             if constexpr (KS == 1) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
             else { pix = idx >> P.sh; c = idx & (cpk - 1); }
-            const int iy = (int)(((float)pix + 0.5f) * P.inv_twin), ix = pix - iy * TWin;
+            const int il = P.NI > 1 ? (int)(((float)pix + 0.5f) * inv_in1) : 0;
+            const int pq = pix - il * in_px1;
+            const int iy = (int)(((float)pq + 0.5f) * P.inv_twin), ix = pq - iy * TWin;
             const int gy = iy0 + iy, gx = ix0 + ix;
-            const bool ok = idx < nchunk && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+            const bool ok = idx < nchunk && il < nimg && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
             if constexpr (VCAT) {  // 1-D: gx = flattened (image, y, x) of the full-resolution level
                 const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
                 const int yy = r / P.up_W, xx = r - yy * P.up_W;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                 goff[k] = ok ? (unsigned)((sp * P.in_cs + c * 4) * 4) : NOPIX;
                 goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + c * 4) * 4) : NOPIX;
             } else {
-                goff[k] = ok ? (unsigned)((((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+                goff[k] = ok ? (unsigned)(((int64_t)il * P.in_bs + ((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
             }
         }
     }
@@ -297,16 +307,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         for (int i = 0; i < MFM2; ++i) {
             const int p = (wp2 + WP2 * i) * 16 + pl;
             if (p >= npix) continue;
-            const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
+            const int il = P.NI > 1 ? (int)(((float)p + 0.5f) * inv_tpi) : 0;
+            const int pq = p - il * tpi;
+            const int ty = (int)(((float)pq + 0.5f) * P.inv_tw), tx = pq - ty * P.TW;
             const int oy = oy0 + ty, ox = ox0 + tx;
-            if (oy >= P.Hout || ox >= P.Wout) continue;
+            if (oy >= P.Hout || ox >= P.Wout || il >= nimg) continue;
             const int64_t opix = (int64_t)oy * P.Wout + ox;
             float v[4] = {acc2[i][0] + bv2.x, acc2[i][1] + bv2.y, acc2[i][2] + bv2.z, acc2[i][3] + bv2.w};
             if (P.act2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
             }
-            int64_t ob = b, opx = opix;
+            int64_t ob = b + il, opx = opix;
             if (P.out2_hw > 0) { ob = opx / P.out2_hw; opx -= ob * P.out2_hw; }
             float *op = P.out2 + ob * P.out2_bs + opx * P.out2_cs + P.out2_co + c2;
             if (full2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
@@ -326,9 +338,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     for (int mf = 0; mf < MFM; ++mf) {
         const int p = (wp + WP * mf) * 16 + pl;
         if (p >= npix) continue;
-        const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
+        const int il = P.NI > 1 ? (int)(((float)p + 0.5f) * inv_tpi) : 0;
+        const int pq = p - il * tpi;
+        const int ty = (int)(((float)pq + 0.5f) * P.inv_tw), tx = pq - ty * P.TW;
         const int oy = oy0 + ty, ox = ox0 + tx;
-        if (oy >= P.Hout || ox >= P.Wout) continue;
+        if (oy >= P.Hout || ox >= P.Wout || il >= nimg) continue;
         const int64_t opix = (int64_t)oy * P.Wout + ox;
         float v[4] = {acc[mf][0] + bv.x, acc[mf][1] + bv.y, acc[mf][2] + bv.z, acc[mf][3] + bv.w};
         if (P.act) {
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
         }
         if (P.res) {
-            const float *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + cbase;
+            const float *rp = P.res + (int64_t)(b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase;
             if (full) {
                 const float4 rv = *reinterpret_cast<const float4 *>(rp);
                 v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                     if (cbase + j < P.cout) v[j] = rp[j] + v[j];
             }
         }
-        int64_t ob = b, opx = opix;
+        int64_t ob = b + il, opx = opix;
         if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }
         float *op = P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
         if (full && ((P.out_cs | P.out_co) & 3) == 0) {
@@ -365,7 +379,7 @@ static int ilog2_(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 static int c32_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 4) + 3) / 4; }
 static int c32_mfm_max(int WC) { return WC == 4 ? 7 : (WC == 2 ? 4 : 2); }  // 224 / 256 / 256 pixels per tile
 static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
-static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
+static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 6 : 5); }
 
 Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat) {
     Conv32Tiling t;
@@ -383,7 +397,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     const int chunk_cap = (vcat ? 4 : c32_maxld(ks, in_u8)) * kNW * 64;  // 16-B chunks one stage may hold
     if (ks == 1) {  // 1-D: the caller flattens batch x pixels
         while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * c32_ksteps(1, t.CK) * 1024 > 78 * 1024)) t.CK /= 2;
-        t.TH = 1; t.TW = maxpix; t.MFM = MFMX;
+        t.TH = 1; t.TW = maxpix; t.MFM = MFMX; t.NI = 1;
         return t;
     }
     const int PST = t.CK * 4 + 16;
@@ -400,7 +414,16 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_th = th; }
     }
     t.TH = best_th;
-    t.MFM = std::max(((t.TH * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
+    t.NI = 1;
+    if (!in_u8 && t.TH == Hout && t.TW == Wout && Hout * Wout * 2 <= maxpix) {
+        // a small map (the 128-px scale's 8 x 8 / 4 x 4 levels): one tile = NI whole images, as many as the fragment budget, the LDS
+        // tile and the staging plan take -- a tile of ONE such map would leave most of the workgroup's fragments empty
+        const int64_t in1 = (int64_t)((Hout - 1) * stride + ks) * ((Wout - 1) * stride + ks);
+        int ni = maxpix / (Hout * Wout);
+        while (ni > 1 && (ni * in1 * PST + t.WC * c32_ksteps(ks, t.CK) * 1024 > 78 * 1024 || ni * in1 * (t.CK / 4) > chunk_cap)) --ni;
+        t.NI = ni;
+    }
+    t.MFM = std::max(((t.NI * t.TH * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
     return t;
 }
 
@@ -441,7 +464,7 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
 
 size_t conv32_lds_bytes(const Conv32Launch &L) {
     const int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    size_t lds = (((size_t)THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_ksteps(L.ks, L.CK) * 1024;  // activation tile + stage weights
+    size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_ksteps(L.ks, L.CK) * 1024;  // activation tile + stage weights
     if (L.tail_cout > 0) lds = std::max(lds, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
     return lds;
 }
@@ -508,7 +531,10 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2_(L.CK / 4);
     if ((4 << P.sh) != L.CK && !(L.ks == 1 && L.CK == 48 && !L.up_c && !L.in_u8)) return hipErrorInvalidValue;
     const int WP = kNW / L.WC;
-    if (L.MFM < 1 || L.MFM > c32_mfm_max(L.WC) || L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
+    const int NI = std::max(1, L.NI);
+    if (L.MFM < 1 || L.MFM > c32_mfm_max(L.WC) || NI * L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
+    if (NI > 1 && (L.ks != 3 || L.in_u8 || L.up_c || L.tiles_x != 1 || L.tiles_y != 1 || L.TH != L.Hout || L.TW != L.Wout || L.out_hw || L.tail_out_hw)) return hipErrorInvalidValue;
+    P.NI = NI; P.B = L.B;
     const int cin_eff = L.in_u8 ? 4 : L.cin;
     if (!L.in_u8 && (L.cin % L.CK || (L.in.cs & 3) || (L.in.co & 3))) return hipErrorInvalidValue;
     if (L.in_u8 && (L.CK != 4 || (L.cin != 3 && L.cin != 4) || !L.lut)) return hipErrorInvalidValue;
@@ -516,7 +542,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.nstage = (cin_eff + L.CK - 1) / L.CK;
     P.kst = c32_ksteps(L.ks, L.CK);
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw;
-    const int64_t ntiles = (int64_t)L.B * L.tiles_y * L.tiles_x;
+    const int64_t ntiles = NI > 1 ? ((int64_t)L.B + NI - 1) / NI : (int64_t)L.B * L.tiles_y * L.tiles_x;
     P.ncb = (L.cout + 16 * L.WC - 1) / (16 * L.WC);
     if (ntiles < 1 || (ntiles + 7) / 8 * 8 * P.ncb >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
@@ -524,7 +550,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
     {
-        int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 4;  // from the slice's first element to the end of the image
+        int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 4 + (int64_t)(NI - 1) * L.in.bs * 4;  // from the slice's first element to the end of the (last) image
         if (L.up_c > 0) {  // virtual [upsample | skip] concat: 1-D 1x1 launches over plain NHWC sources only
             if (L.ks != 1 || L.in_u8 || L.B != 1 || L.Hin != 1 || !L.in2.p || L.up_c % L.CK || L.up_c >= L.cin || (L.up_W & 1) || (L.up_HW % L.up_W) ||
                 ((L.up_HW / L.up_W) & 1) || L.Win % L.up_HW || (L.in2.cs & 3) || (L.in2.co & 3))
@@ -538,10 +564,10 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
         if (!L.in_u8 && (span <= 0 || span >= (1ll << 32) - 65536)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = L.in_u8 ? 0u : (unsigned)span;
     }
-    if ((int64_t)THin * TWin * (L.in_u8 ? 1 : L.CK / 4) > (int64_t)(L.up_c > 0 ? 4 : c32_maxld(L.ks, L.in_u8)) * kNW * 64) return hipErrorInvalidValue;  // staging plan: chunks per thread
+    if ((int64_t)NI * THin * TWin * (L.in_u8 ? 1 : L.CK / 4) > (int64_t)(L.up_c > 0 ? 4 : c32_maxld(L.ks, L.in_u8)) * kNW * 64) return hipErrorInvalidValue;  // staging plan: chunks per thread
     int tail_wc2 = 0;
     if (L.tail_cout > 0) {
-        const Conv32Tiling t{L.TH, L.TW, L.CK, L.WC, L.MFM};
+        const Conv32Tiling t{L.TH, L.TW, L.CK, L.WC, L.MFM, NI};
         if (!conv32_tail_supported(t, L.cout, L.tail_cout) || P.ncb != 1 || !L.tail_w || !L.tail_b || !L.tail_out.p || L.res.p) return hipErrorInvalidValue;
         tail_wc2 = L.tail_cout > 32 ? 4 : (L.tail_cout > 16 ? 2 : 1);
         if (L.WC == 1 && tail_wc2 != 1) return hipErrorInvalidValue;
@@ -591,15 +617,24 @@ __global__ __launch_bounds__(256) void k_stem_f32(const Stem32Params P) {
     __syncthreads();
     const int iy0 = 2 * oy0 - 1;
     const uint8_t *src = P.in + (int64_t)b * P.in_bs;
-    for (int i = tid; i < (2 * R + 1) * dpr; i += 256) {
+    // every load of the stripe is issued before the first conversion (a load -> convert -> store loop paid one memory latency per dword:
+    // 11 of them per thread); rows above the image read as byte 0 = table entry 0.0f = the zero padding
+    constexpr int MAXI = 16;  // dwords per thread: 9 rows x Win * CIN / 4 <= 16 * 256 (stem32_supported)
+    const int total = (2 * R + 1) * dpr;
+    unsigned wv[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int i = tid + k * 256;
         const int lr = i / dpr, d = i - lr * dpr;
         const int iy = iy0 + lr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < P.Hin) {
-            const unsigned wv = *reinterpret_cast<const unsigned *>(src + (int64_t)iy * rowb + d * 4);
-            v = make_float4(slut[wv & 255u], slut[(wv >> 8) & 255u], slut[(wv >> 16) & 255u], slut[wv >> 24]);
-        }
-        *reinterpret_cast<float4 *>(sst + lr * RS + 4 + d * 4) = v;
+        wv[k] = (i < total && iy >= 0 && iy < P.Hin) ? *reinterpret_cast<const unsigned *>(src + (int64_t)iy * rowb + d * 4) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int i = tid + k * 256;
+        const int lr = i / dpr, d = i - lr * dpr;
+        if (i < total)
+            *reinterpret_cast<float4 *>(sst + lr * RS + 4 + d * 4) = make_float4(slut[wv[k] & 255u], slut[(wv[k] >> 8) & 255u], slut[(wv[k] >> 16) & 255u], slut[wv[k] >> 24]);
     }
     // per-lane constants: weights (A operand: cout = lane & 15 of fragment nf, k = 4 t + g) and the LDS offset of tap k
     float wA[NF][KST];
@@ -660,7 +695,7 @@ static int stem32_rs(int Win, int cin) { return (4 + Win * cin + 3) & ~3; }
 bool stem32_supported(int cin, int cout, int ks, int stride, int Hin, int Win) {
     if (ks != 3 || stride != 2 || (cin != 3 && cin != 4) || (cout != 16 && cout != 32)) return false;
     if (Hin % 8 || Win % 32) return false;  // 4-row stripes of the output, 16-pixel fragments, 16-byte input chunks
-    return (size_t)(9 * stem32_rs(Win, cin) + 256) * 4 <= 64 * 1024;
+    return (size_t)(9 * stem32_rs(Win, cin) + 256) * 4 <= 64 * 1024 && 9 * Win * cin / 4 <= 16 * 256;
 }
 
 // [fragment nf][k step t][lane]: weight of cout 16 nf + (lane & 15) for k = 4 t + (lane >> 4), k = (ky * 3 + kx) * cin + c over the

@@ -66,9 +66,17 @@ class YOLO:
 
     weights: path to an "OBBW" blob, raw bytes, or any object with .to_blob() (the trained .pt files of the reference are
     Google-Drive links and need ultralytics to un-pickle: not available offline).
-    imgsz: the size the checkpoint was trained at (Ultralytics reads it from the checkpoint: 416 / 128 here)."""
+    imgsz: the size the checkpoint was trained at (Ultralytics reads it from the checkpoint: 416 / 128 here).
+    precision: the arithmetic of the forward.
+      "f32" (default)  fp32 weights, activations and accumulation end to end (exact-f32 MFMA): what `model(net_input, conf=...)` computes in
+                       Detect_OBB.py:79-83 (Ultralytics' half=False).  Detections agree with the fp32 reference pipeline one to one (same count,
+                       classes and order up to confidence near-ties; confidences within 2e-4, corners within 0.1 px: tests/test_gpu_fp32.py).
+      "f16"            opt-in fast mode (4-5x the tiles/s): fp16 storage, fp32 accumulation -- what Ultralytics' half=True does.  Head logits
+                       move by ~1e-2, so candidates within that of a hard threshold (conf 0.25 / 0.70, NMS 0.7, merge 0.4) flip: >= 95 % of the
+                       detections of a dense scene match the fp32 pipeline (IoU >= 0.5, |d conf| <= 0.12), not all of them.
+      "bf16"           like "f16" with bf16 storage: 8 significand bits, ~78 % agreement; only for experiments."""
 
-    def __init__(self, weights, imgsz=416, device=None, precision="f16", names=None):
+    def __init__(self, weights, imgsz=416, device=None, precision="f32", names=None):
         if not torch.cuda.is_available():
             raise RuntimeError("YOLO: no HIP device visible; this implementation has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)

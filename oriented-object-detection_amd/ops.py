@@ -384,6 +384,30 @@ def rotated_tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, m
     return tl, tb, ts, fg.bool(), ti
 
 
+def conv_dgrad_bf16(dy, weight):
+    """dy bf16 [B,H,W,cout] (device, NHWC), weight fp32 [cout,cin,k,k] (any device; repacked on the host per call) -> dx bf16 [B,H,W,cin]: the
+    input gradient of the stride-1 `same` convolution, on the forward's bf16 MFMA kernel with flipped / transposed weights."""
+    d = _chk(dy, torch.bfloat16, "dy")
+    B, H, W, cout = d.shape
+    w = weight.detach().float().cpu().contiguous()
+    assert w.shape[0] == cout and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
+    cin, ks = int(w.shape[1]), int(w.shape[2])
+    dx = torch.empty((B, H, W, cin), dtype=torch.bfloat16, device=d.device)
+    _call("obb_conv_dgrad_bf16", ctx(d.device), _p(d), w.numpy().ctypes.data_as(_lib.c_fp), B, H, W, cin, cout, ks, _p(dx), _stream())
+    return dx
+
+
+def conv_wgrad_bf16(x, dy, ks):
+    """x bf16 [B,H,W,cin], dy bf16 [B,H,W,cout] (NHWC, device) -> dw fp32 [cout,cin,ks,ks]: the weight gradient of the stride-1 `same`
+    convolution, fp32 accumulation, deterministic."""
+    xx, d = _chk(x, torch.bfloat16, "x"), _chk(dy, torch.bfloat16, "dy")
+    B, H, W, cin = xx.shape
+    cout = d.shape[3]
+    dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=xx.device)
+    _call("obb_conv_wgrad_bf16", ctx(xx.device), _p(xx), _p(d), B, H, W, cin, cout, int(ks), _p(dw), _stream())
+    return dw
+
+
 def tile_survivors(det, count, lb, tile_ids, rects, margin, iou_thr, strike_cls=1):
     """det float32[B, max_det, 7] + count int32[B] (decode_nms) -> (records int32[B * max_det, 12] (capacity), tile_off int32[B + 1],
     n_records int32[1]), all on the device: result construction, per-detection body (border filter `margin`), per-tile merge at `iou_thr`

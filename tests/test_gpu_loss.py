@@ -141,7 +141,7 @@ def test_rotated_task_aligned_assigner(bs, n_max, seed):
     """obb_rotated_tal_assign against the torch restatement of ultralytics' RotatedTaskAlignedAssigner (oracle/loss.py, fp32 on the CPU):
     64 images x 3549 anchors x up to 40 boxes.  The discrete outputs (foreground mask, gt index, label, box) must be identical except
     where the decision was a numerical near-tie in the reference's own metrics (topk boundary or arg-max of the overlaps within 1e-5
-    relative: device libm vs torch differ in the last bits); the scores within 2e-5."""
+    relative: device libm vs torch differ in the last bits); the scores within 5e-5."""
     import oriented_object_detection_amd  # noqa: F401
     from oriented_object_detection_amd import ops
     pds, pdb, anc, gtl, gtb, mgt = _assign_case(seed, bs, n_max)
@@ -171,7 +171,33 @@ def test_rotated_task_aligned_assigner(bs, n_max, seed):
     assert float((tb[same] - e_tb[same]).abs().max()) == 0.0
     ds = (ts - e_ts).abs()[same]
     print("target_scores: max |d|", float(ds.max()), "max", float(e_ts.max()))
-    assert float(ds.max()) <= 2e-5 * max(1.0, float(e_ts.max()))
+    assert float(ds.max()) <= 5e-5 * max(1.0, float(e_ts.max()))  # (overlap ** 6: six times the relative error of the device's log / exp / sqrt vs torch's)
     # no ground truth at all -> everything background
     z = ops.rotated_tal_assign(t(pds).cuda(), t(pdb).cuda(), t(anc).cuda(), t(gtl[:, :0]).cuda(), t(gtb[:, :0]).cuda(), t(mgt[:, :0]).cuda())
     assert int(z[3].sum()) == 0 and float(z[2].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- f1, slice 3: convolution backward
+@pytest.mark.parametrize("B,H,W,cin,cout,ks", [(8, 52, 52, 64, 64, 3), (5, 26, 26, 128, 64, 1), (3, 13, 13, 64, 128, 3), (2, 26, 26, 128, 128, 3), (4, 52, 52, 64, 64, 1)])
+def test_conv_backward_bf16(B, H, W, cin, cout, ks):
+    """dgrad + wgrad of a stride-1 `same` convolution (bf16 tensors, fp32 accumulation) against torch.autograd in fp32 on the SAME
+    bf16-rounded values: what differs is the summation order (and the final bf16 rounding of dx)."""
+    import torch.nn.functional as F
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H + cin + ks)
+    x = (torch.randn((B, cin, H, W), generator=g) * 0.7).bfloat16()
+    w = (torch.randn((cout, cin, ks, ks), generator=g) * (1.0 / (cin * ks * ks) ** 0.5)).bfloat16()
+    dy = torch.randn((B, cout, H, W), generator=g).bfloat16()
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    F.conv2d(xr, wr, padding=ks // 2).backward(dy.float())
+    dx = ops.conv_dgrad_bf16(dy.permute(0, 2, 3, 1).contiguous().cuda(), w.float())
+    dw = ops.conv_wgrad_bf16(x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda(), ks)
+    e_dx = (dx.float().cpu().permute(0, 3, 1, 2) - xr.grad).abs()
+    e_dw = (dw.cpu() - wr.grad).abs()
+    sx, sw = float(xr.grad.abs().max()), float(wr.grad.abs().max())
+    print(f"{B}x{H}x{W} {cin}->{cout} k{ks}: dx max |d| / max {float(e_dx.max()) / sx:.2e} (bf16 output), dw max |d| / max {float(e_dw.max()) / sw:.2e}")
+    assert float(e_dx.max()) <= 6e-3 * sx  # one bf16 rounding of the result (2^-8 relative) + summation order
+    assert float(e_dw.max()) <= 2e-5 * sw  # fp32 sums of exact bf16 products: summation order only
+    again = ops.conv_wgrad_bf16(x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda(), ks)
+    assert torch.equal(again, dw)  # deterministic

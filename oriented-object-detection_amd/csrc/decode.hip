@@ -319,6 +319,9 @@ struct HeavyScratch {  // per tile, stride AS rows (AS = A rounded up to 4)
     int32_t *ncand;    // [B] candidates of a flagged tile
     int32_t *flist;    // [B] flagged tiles
     int32_t *nflag;    // [1]
+    int32_t *sidx;     // sorted order: position in the candidate list
+    int32_t *nkept;    // [B] kept rows of the rounds processed so far
+    int32_t *done;     // [B] snapshot of nkept >= max_det taken between rounds
 };
 
 // class scores of one anchor: three 16-byte loads instead of nc scalar ones (rows are padded to a multiple of 4 floats, columns past nc
@@ -537,6 +540,114 @@ __global__ __launch_bounds__(256) void k_heavy_nms(int A, float iou_thres, int m
     }
 }
 
+// ---- the round form of the heavy path (metrics mode: thousands of candidates per tile, of which only the first max_det survivors in
+//      score order are ever output).  A Fast-NMS row is kept iff NO higher-scored row overlaps it -- kept or not -- so the keep flag of
+//      row r needs rows [0, r) only: the rows are processed in rounds of kRoundRows in score order and a tile stops at the first round
+//      boundary where it has max_det survivors.  Nothing behind that boundary is decoded or compared; the rows in front of it get exactly
+//      the flags of the all-rows form above (k_heavy_sort / k_heavy_nms stay as its parity reference).
+static constexpr int kRoundRows = 512;
+
+// stable descending sort of a flagged tile's candidate scores: one workgroup per tile, bitonic network on 64-bit keys in LDS
+// key = score bits (positive floats order like their bit patterns) << 32 | ~position (ties: the earlier candidate = lower anchor first)
+__global__ __launch_bounds__(1024) void k_heavy_bitonic(int A, int max_det, HeavyScratch S) {
+    extern __shared__ unsigned long long skey[];
+    const int tid = threadIdx.x;
+    const int64_t AS = (A + 3) & ~3;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const int n = S.ncand[b];
+        int NP = 1024;
+        while (NP < n) NP <<= 1;
+        const float *gscore = S.cscore + (int64_t)b * AS;
+        __syncthreads();
+        for (int i = tid; i < NP; i += 1024)
+            skey[i] = i < n ? ((unsigned long long)__float_as_uint(gscore[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i) : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= NP; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < NP; i += 1024) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = skey[i], c = skey[l];
+                        const bool desc = (i & k) == 0;  // descending blocks first: the final order is descending
+                        if (desc ? a < c : a > c) { skey[i] = c; skey[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        int32_t *sidx = S.sidx + (int64_t)b * AS;
+        for (int i = tid; i < n; i += 1024) sidx[i] = (int32_t)(0xffffffffu - (unsigned)(skey[i] & 0xffffffffull));
+        if (tid == 0) { S.nkept[b] = 0; S.done[b] = 0; }
+    }
+}
+
+// rows [r0, r1) of every unfinished flagged tile: decode + covariance terms into the sorted arrays; also takes the `done` snapshot
+__global__ __launch_bounds__(256) void k_heavy_decode_rows(const float *__restrict__ head, int A, int nc, int h, int w, int r0, int r1, int max_det, HeavyScratch S) {
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4;
+    const int64_t AS = (A + 3) & ~3;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const bool fin = S.nkept[b] >= max_det;  // (complete: the previous round's kernel has ended)
+        if (blockIdx.y == 0 && threadIdx.x == 0) S.done[b] = fin;
+        if (fin) continue;
+        const int n = S.ncand[b];
+        const int rank = r0 + blockIdx.y * 256 + threadIdx.x;
+        if (rank >= r1 || rank >= n) continue;
+        const int i = S.sidx[(int64_t)b * AS + rank];
+        const int a = S.cand[(int64_t)b * AS + i];
+        const int cls = S.ccls[(int64_t)b * AS + i];
+        float x, y, ww, hh, t;
+        decode_anchor(head + ((int64_t)b * A + a) * no, a, nc, h, w, x, y, ww, hh, t);
+        const int64_t r = (int64_t)b * AS + rank;
+        const float c = (float)cls * kMaxWh;
+        S.rb[r] = make_rbox(x + c, y + c, ww, hh, t);
+        float *sb = S.sbox + r * 5;
+        sb[0] = x; sb[1] = y; sb[2] = ww; sb[3] = hh; sb[4] = t;
+        S.sscore[r] = S.cscore[(int64_t)b * AS + i];
+        S.scls[r] = (uint8_t)cls;
+    }
+}
+
+// Fast-NMS flags of rows [r0, r1): one wave per row against every earlier row; the round's survivors are counted into nkept
+__global__ __launch_bounds__(256) void k_heavy_nms_rows(int A, float iou_thres, int r0, int r1, float kq, float bdmax, HeavyScratch S) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gw = blockIdx.y * 4 + (tid >> 6), nw = gridDim.y * 4;
+    const int64_t AS = (A + 3) & ~3;
+    const bool skip_other_cls = iou_thres > 1e-3f;
+    const int nflag = *S.nflag;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        if (S.done[b]) continue;
+        const int n = min(S.ncand[b], r1);
+        const RBox *rb = S.rb + (int64_t)b * AS;
+        const uint8_t *scls = S.scls + (int64_t)b * AS;
+        uint8_t *keep = S.keep + (int64_t)b * AS;
+        int kept = 0;
+        for (int r = r0 + gw; r < n; r += nw) {
+            const RBox q = rb[r];
+            const uint8_t cq = scls[r];
+            bool hit = false;
+            for (int i0 = 0; i0 < r; i0 += 64) {
+                const int i = i0 + lane;
+                bool hh = false;
+                if (i < r && !(skip_other_cls && scls[i] != cq)) {
+                    const RBox p = rb[i];
+                    if (!far_apart(p, q, kq)) {
+                        const int dec = bdmax > 0.0f ? probiou_fast_decision(p, q, bdmax) : 0;
+                        hh = dec > 0 || (dec == 0 && probiou(p, q) >= iou_thres);
+                    }
+                }
+                if (__ballot(hh)) { hit = true; break; }
+            }
+            if (lane == 0) keep[r] = (uint8_t)!hit;
+            kept += !hit;
+        }
+        if (lane == 0 && kept) atomicAdd(&S.nkept[b], kept);
+    }
+}
+
 // first max_det survivors of a flagged tile in score order -> output rows
 __global__ __launch_bounds__(256) void k_heavy_out(int A, int max_det, int max_nms, HeavyScratch S, float *__restrict__ out, int32_t *__restrict__ count) {
     __shared__ int wave_tot[16];
@@ -710,10 +821,11 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
     S.sbox = (float *)ctx->workspace(WS_NMS_D, rows * 20);
     S.rb = (RBox *)ctx->workspace(WS_GEOM_A, rows * sizeof(RBox));
     uint8_t *bytes = (uint8_t *)ctx->workspace(WS_GEOM_B, rows * 3);
-    int32_t *ints = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)2 * B + 64));
-    if (!S.cand || !S.cscore || !S.sscore || !S.sbox || !S.rb || !bytes || !ints) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
+    int32_t *ints = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)4 * B + 64));
+    S.sidx = (int32_t *)ctx->workspace(WS_GEOM_D, rows * 4);
+    if (!S.cand || !S.cscore || !S.sscore || !S.sbox || !S.rb || !bytes || !ints || !S.sidx) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
     S.ccls = bytes; S.scls = bytes + rows; S.keep = bytes + 2 * rows;
-    S.ncand = ints; S.flist = ints + B; S.nflag = ints + 2 * (size_t)B;
+    S.ncand = ints; S.flist = ints + B; S.nkept = ints + 2 * (size_t)B; S.done = ints + 3 * (size_t)B; S.nflag = ints + 4 * (size_t)B;
     OBB_HIP(ctx, hipMemsetAsync(S.nflag, 0, sizeof(int32_t), st));
     // largest logit an anchor needs to be worth the exact class scores: logit(conf) minus a guard band far above the error of sigmoid_f
     float gate = -INFINITY;
@@ -727,11 +839,34 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
     OBB_LAUNCH_CHECK(ctx);
     // tiles above kCandCap candidates (device-side list; every block of these launches exits at once when the list is empty)
     const int slots = std::min<int>(kHeavySlots, B);
-    hipLaunchKernelGGL(k_heavy_sort, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, 30000, S);
-    OBB_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_heavy_nms, dim3((unsigned)slots, 64), dim3(256), 0, st, A, iou_thres, 30000, kq, bdmax, S);
-    OBB_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_heavy_out, dim3((unsigned)slots), dim3(256), 0, st, A, max_det, 30000, S, out, count);
+    int NPmax = 1024;
+    while (NPmax < A) NPmax <<= 1;
+    if ((size_t)NPmax * 8 <= 128 * 1024) {
+        // round form: sort once, then rows in score order, kRoundRows at a time, until every tile has its max_det survivors
+        static bool attr_set = false;
+        if (!attr_set) {
+            OBB_HIP(ctx, hipFuncSetAttribute((const void *)k_heavy_bitonic, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_heavy_bitonic, dim3((unsigned)std::min<int>(B, 256)), dim3(1024), (size_t)NPmax * 8, st, A, max_det, S);
+        OBB_LAUNCH_CHECK(ctx);
+        // rounds of 512, 1024, then 2048 rows (multiples of k_heavy_out's 256-row chunks): most tiles finish inside the first two, and with
+        // nothing flagged (the usual predict-mode batch) the launches are empty -- few of them, on small grids
+        const int gx = std::min<int>(B, 256);
+        for (int r0 = 0, size = kRoundRows; r0 < A; size = std::min(2 * size, 2048)) {
+            const int r1 = std::min(A, r0 + size);
+            hipLaunchKernelGGL(k_heavy_decode_rows, dim3((unsigned)gx, (unsigned)cdiv(r1 - r0, 256)), dim3(256), 0, st, head, A, nc, h, w, r0, r1, max_det, S);
+            hipLaunchKernelGGL(k_heavy_nms_rows, dim3((unsigned)gx, 16), dim3(256), 0, st, A, iou_thres, r0, r1, kq, bdmax, S);
+            OBB_LAUNCH_CHECK(ctx);
+            r0 = r1;
+        }
+    } else {  // more anchors than the LDS sort takes (inputs above ~900 x 900): the all-rows form
+        hipLaunchKernelGGL(k_heavy_sort, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, 30000, S);
+        OBB_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(k_heavy_nms, dim3((unsigned)slots, 64), dim3(256), 0, st, A, iou_thres, 30000, kq, bdmax, S);
+        OBB_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_heavy_out, dim3((unsigned)std::min<int>(B, 256)), dim3(256), 0, st, A, max_det, 30000, S, out, count);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

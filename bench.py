@@ -144,7 +144,7 @@ def main():
         return make_weights.path_for("n", 12, ch, seed)
 
     B = args.batch
-    s_fwd, s_post = torch.cuda.Stream(), torch.cuda.Stream()
+    s_fwd, s_post, s_pre = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 
     class Scale:
         """one tile size of a workload: the model, its resident synthetic tiles, double-buffered heads, tile rectangles"""
@@ -152,9 +152,10 @@ def main():
         def __init__(self, model, px, n, seed, rects, tile_ids, channels=3):
             self.model, self.px, self.n = model, px, n
             self.tiles = torch.as_tensor(np.random.default_rng(seed).integers(0, 256, (n, px, px, 3), dtype=np.uint8)).to(dev)
-            # 4-channel mode: the input builder runs on the forward's stream in front of it (on a stream of its own, under the previous
-            # step's forward, it costs more than it hides: the forward's two chains and the post-processing stream already occupy the queues)
-            self.tiles4 = torch.zeros((n, px, px, 4), dtype=torch.uint8, device=dev) if channels == 4 else None
+            # 4-channel mode: the input builder of step k + 1 runs on a stream of its own under the forward of step k (double-buffered
+            # 4-channel tiles); it is part of the step, outside the forward's event pair
+            self.tiles4 = [torch.zeros((n, px, px, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if channels == 4 else None
+            self.ev_pre, self.ev_used = [None, None], [None, None]
             A = ops.model_info(px, px)["anchors"]
             self.heads = [torch.zeros((n, A, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
             self.rects_dev = torch.as_tensor(rects).to(dev)
@@ -162,14 +163,31 @@ def main():
             self.cfg = D.Config(tile_sizes=(px,), overlaps=(100 if px > 128 else 30,))
             self.ev = []
 
+        def prepare(self, k):  # on s_pre: build_multich of step k (no-op for 3-channel models)
+            if self.tiles4 is None or self.ev_pre[k % 2] is not None:
+                return
+            with torch.cuda.stream(s_pre):
+                if self.ev_used[k % 2] is not None:
+                    s_pre.wait_event(self.ev_used[k % 2])  # the forward of step k - 2 has consumed this buffer
+                ops.build_multich(self.tiles, out=self.tiles4[k % 2])
+                self.ev_pre[k % 2] = torch.cuda.Event()
+                self.ev_pre[k % 2].record()
+
         def forward(self, k, timed):  # on s_fwd
             self.model._ensure_active()
             e0, e1 = torch.cuda.Event(enable_timing=timed), torch.cuda.Event(enable_timing=timed)
+            src = self.tiles
             if self.tiles4 is not None:
-                ops.build_multich(self.tiles, out=self.tiles4)  # inside the step, outside the forward's event pair
+                self.prepare(k)
+                s_fwd.wait_event(self.ev_pre[k % 2])
+                self.ev_pre[k % 2] = None
+                src = self.tiles4[k % 2]
             e0.record()
-            head = ops.forward(self.tiles if self.tiles4 is None else self.tiles4, out=self.heads[k % 2])
+            head = ops.forward(src, out=self.heads[k % 2])
             e1.record()
+            if self.tiles4 is not None:
+                self.ev_used[k % 2] = e1
+                self.prepare(k + 1)  # overlaps this forward
             if timed:
                 self.ev.append((e0, e1))
             return head
@@ -216,6 +234,7 @@ def main():
             cur = torch.cuda.current_stream()
             s_fwd.wait_stream(cur)
             s_post.wait_stream(cur)
+            s_pre.wait_stream(cur)
             res, pending, dones = (0, 0), None, [None, None]
             for k in range(n):
                 if dones[k % 2] is not None:
@@ -235,6 +254,9 @@ def main():
                 res = r[:2]
             cur.wait_stream(s_post)
             cur.wait_stream(s_fwd)
+            cur.wait_stream(s_pre)
+            for sc in scales:  # (a prepared but unused buffer of the step after the last one: drop it, the next run starts clean)
+                sc.ev_pre, sc.ev_used = [None, None], [None, None]
             return res
 
         if warmup:

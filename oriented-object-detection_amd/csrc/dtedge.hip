@@ -693,7 +693,7 @@ extern "C" int obb_build_multich(obb_ctx *ctx, const uint8_t *bgr, int32_t B, in
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t acc_bytes = up((size_t)h * pitch * 4), tt_bytes = up((size_t)(h + 1) * pitch * 4), edge_bytes = up((size_t)h * pitch);
     const size_t stats_bytes = up(sizeof(DtStats) * (size_t)B);
-    char *scratch = (char *)ctx->workspace(WS_GEOM_E, (acc_bytes + tt_bytes + edge_bytes) * (size_t)B + stats_bytes);
+    char *scratch = (char *)ctx->workspace(WS_DT, (acc_bytes + tt_bytes + edge_bytes) * (size_t)B + stats_bytes);
     if (!scratch) return set_error(ctx, OBB_ERR_HIP, "obb_build_multich: workspace allocation failed");
     float *acc = reinterpret_cast<float *>(scratch);
     int *tt = reinterpret_cast<int *>(scratch + acc_bytes * (size_t)B);

@@ -453,10 +453,51 @@ struct Builder {
         P.named[name] = out;
     }
 
+    // fp32 mode: DWConv 3x3 -> Conv 1x1 [-> plain 1x1 into the head rows] as ONE launch of k_conv_f32 (DW variant: the depthwise output exists
+    // only in LDS).  Returns false (nothing emitted) if the shapes have no kernel.
+    bool dwpw32(const std::string &dwname, const std::string &pwname, Slice in, int H, int W, Slice out, const char *tailname, int head_level) {
+        const ConvRecord *rd = rec(dwname), *rp = rec(pwname), *rt = tailname ? rec(tailname) : nullptr;
+        if (!(M.tail && M.o.dwpw) || !rd || !rp || (tailname && !rt) || err) return false;
+        if (in.buf < 0 || P.bufs[in.buf].virt || rd->g != rd->c1 || rd->c1 != rd->c2 || rd->k != 3 || rd->s != 1 || rd->c1 != in.C || rp->g != 1 || rp->k != 1 || rp->s != 1 ||
+            rp->c1 != in.C)
+            return false;
+        if (rt && (rt->g != 1 || rt->k != 1 || rt->s != 1 || rt->act || rt->c1 != rp->c2 || head_level < 0)) return false;
+        if (!rt && (out.buf < 0 || P.bufs[out.buf].virt || out.C != rp->c2)) return false;
+        const Conv32Tiling t = plan_dwpw32(in.C, rp->c2, H, W);
+        if (t.TH == 0 || (rt && !conv32_tail_supported(t, rp->c2, rt->c2)) || (rt && rt->c2 > 16)) return false;
+        Op op;
+        op.type = OP_CONV32; op.name = dwname + "+" + pwname + (rt ? std::string("+") + tailname : std::string()); op.in = in; op.out = out;
+        op.H = H; op.W = W; op.Ho = H; op.Wo = W; op.head_level = rt ? head_level : -1; op.one_d = false;
+        Conv32Launch &L = op.c32;
+        L.ks = 1; L.stride = 1; L.cin = in.C; L.cout = rp->c2; L.act = rp->act; L.dw = 1; L.dw_act = rd->act;
+        L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM; L.NI = 1;
+        L.Hin = L.Hout = H; L.Win = L.Wout = W;
+        L.tiles_y = (H + t.TH - 1) / t.TH; L.tiles_x = 1;
+        L.wpk = upload(pack_dwpw32_weights(rp->w, rp->c2, in.C, rd->w, rd->b, t));
+        std::vector<float> bias32(((size_t)rp->c2 + 63) / 64 * 64 + 64, 0.f);
+        for (int c = 0; c < rp->c2; ++c) bias32[c] = rp->b[c];
+        L.bias = upload(bias32);
+        op.macs = (double)H * W * (9.0 * in.C + (double)in.C * rp->c2);
+        if (rt) {
+            const Conv32Tiling t2{1, 1, rp->c2, 1, 1, 1};
+            L.tail_w = upload(pack_conv32_weights(rt->w, rt->c2, rp->c2, 1, t2, nullptr, false));
+            std::vector<float> b2(((size_t)rt->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < rt->c2; ++c) b2[c] = rt->b[c];
+            L.tail_b = upload(b2);
+            L.tail_cout = rt->c2; L.tail_act = 0;
+            op.macs += (double)H * W * rt->c1 * rt->c2;
+        }
+        P.macs_per_img += op.macs;
+        P.ops.push_back(op);
+        if (!rt) P.named[pwname] = out;
+        return true;
+    }
+
     // DWConv 3x3 `dwname` -> Conv 1x1 `pwname` [-> plain 1x1 `tailname` into the head tensor] as one stripe kernel (dwpw.hip).
     // Returns false (nothing emitted) if the shapes have no kernel.
     bool dwpw(const std::string &dwname, const std::string &pwname, Slice in, int H, int W, Slice out, const char *tailname = nullptr, int head_level = -1) {
-        const bool on = M.tail && M.o.dwpw && !M.f32;
+        if (M.f32) return dwpw32(dwname, pwname, in, H, W, out, tailname, head_level);
+        const bool on = M.tail && M.o.dwpw;
         const ConvRecord *rd = rec(dwname), *rp = rec(pwname), *rt = tailname ? rec(tailname) : nullptr;
         if (!on || !rd || !rp || (tailname && !rt) || err) return false;
         if (in.buf < 0 || P.bufs[in.buf].blk || P.bufs[in.buf].virt || rd->g != rd->c1 || rd->c1 != rd->c2 || rd->k != 3 || rd->s != 1 || rd->c1 != in.C || !rd->act ||
@@ -1292,8 +1333,8 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
         switch (op.type) {
             case OP_CONV32: {
                 const Conv32Launch &L = op.c32;
-                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d NI%d CK%d WC%d MFM%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
-                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.NI, L.CK, L.WC, L.MFM, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
+                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d NI%d CK%d WC%d MFM%d dw%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
+                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.NI, L.CK, L.WC, L.MFM, L.dw, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
                 break;
             }
             case OP_CONV: {

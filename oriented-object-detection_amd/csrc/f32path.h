@@ -37,6 +37,7 @@ struct Conv32Launch {
     // tiling (plan_conv32): output tile TH x TW (<= 16 * (8 / WC) * MFM pixels), CK input channels per LDS stage, WC of the workgroup's 8
     // waves along cout (16 couts each), the other 8 / WC along the pixel fragments, MFM fragments of 16 pixels per wave
     int TH = 1, TW = 208, CK = 16, WC = 4, MFM = 7;
+    int dw = 0, dw_act = 1;  // dw: a depthwise 3x3 (+ bias, SiLU if dw_act) runs in front of this 1x1 inside the launch (wpk from pack_dwpw32_weights)
     int NI = 1;  // > 1: one tile = NI whole images of a small map (TH x TW = the map; the 8 x 8 / 4 x 4 levels of the 128-px scale)
     int tiles_y = 1, tiles_x = 1;
 };
@@ -45,6 +46,10 @@ struct Conv32Tiling { int TH, TW, CK, WC, MFM, NI; };
 Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat = false);  // vcat: the input is a virtual [upsample | skip] concat
 // true if the 1x1 conv (cout1 -> cout2) can run as the fused tail of a layer tiled as `t`
 bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2);
+// DWConv 3x3 -> Conv 1x1 as one launch (k_conv_f32 DW): tiling (TH = 0: no kernel for the shapes) and the per-stage weight blocks
+// [pw fragments of the stage][9 depthwise taps + bias of the stage's channels]
+Conv32Tiling plan_dwpw32(int cin, int cout, int H, int W);
+std::vector<float> pack_dwpw32_weights(const float *pw_oihw, int cout, int cin, const float *dw_c9, const float *dw_bias, const Conv32Tiling &t);
 // fp32 OIHW -> A-operand order [cout fragment of 16][stage][k16 step][lane][4]: lane (r = lane & 15, g = lane >> 4) holds the weights of
 // cout r for the four k values of its 4-channel chunk q = 4 * step + g (tap = q / (CK/4), channels 4 * (q % (CK/4)) ..+3); element s of
 // the vector feeds MFMA step s.  cout_perm (optional): logical cout -> source row.

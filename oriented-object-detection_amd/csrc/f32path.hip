@@ -38,6 +38,7 @@ struct C32Params {
     const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
+    int dw_act;  // DW: SiLU behind the depthwise conv
     int NI, B;  // NI > 1: a tile = NI whole images of a small map (TH x TW = the map), B images in all
     float inv_twin, inv_tw;
     unsigned in_span_bytes;  // buffer-descriptor range of one image's input slice (its check returns zeros past the end)
@@ -59,10 +60,15 @@ __device__ __forceinline__ float silu32(float x) { return x * __builtin_amdgcn_r
 //     runs from there: the producer's tensor is never written.  Used for the last 1x1 of every head branch and for the cv1 of a
 //     C3k2 block behind its stride-2 conv.
 //   * VCAT: the 1x1 behind [Upsample | skip] reads both sources in place (stage-uniform choice: up_c is a multiple of CK).
-template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL>
+//   * DW (1x1 only): a depthwise 3x3 (+ bias, SiLU) in FRONT of the 1x1, per channel stage: the stage's input tile is staged with a
+//     one-pixel halo, every thread computes depthwise outputs for its (pixel, 4-channel chunk) items straight from that LDS tile (taps in
+//     (ky, kx) order like k_dwconv3_f32, weights from the stage's weight block) and writes them where the 1x1's B operand is read -- the
+//     depthwise tensor never exists in memory (the class branch of the head: DWConv -> Conv 1x1 [-> Conv 1x1 to the head rows]).
+template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL, bool DW = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P) {  // <= 128 VGPRs: two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = NW * 64, WP = NW / WC, PAD = KS / 2;
+    constexpr int SKS = DW ? 3 : KS;  // kernel size the STAGING sees (halo); the MFMA loop sees KS
+    constexpr int NT = NW * 64, WP = NW / WC, PAD = SKS / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the fragment guards below become scalar branches
     const int g = lane >> 4, pl = lane & 15;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     const int t = (lin / P.ncb) * 8 + xcd;
     if (t >= P.ntiles) return;
     const int S = P.stride;
-    const int THin = (P.TH - 1) * S + KS, TWin = (P.TW - 1) * S + KS;
+    const int THin = (P.TH - 1) * S + SKS, TWin = (P.TW - 1) * S + SKS;
     const int PST = P.CK * 4 + 16;  // bytes per staged pixel (+16 B spreads consecutive pixels over the banks)
     const int cpk = P.CK >> 2;
     const int nq = (KS == 3 ? 9 : 1) * cpk;
@@ -101,12 +107,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         const int q = p - il * tpi;
         const int ty = (int)(((float)q + 0.5f) * P.inv_tw);
         const int tx = q - ty * P.TW;
-        pixbase[mf] = p < npix ? (il * in_px1 + (ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
+        if constexpr (DW) pixbase[mf] = (p < npix ? p : 0) * PST;  // (relative to the depthwise-output tile, added below)
+        else pixbase[mf] = p < npix ? (il * in_px1 + (ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
     }
     const int F = cb * WC + wc;  // cout fragment of this wave
     // weights of (cout block cb, stage): WC * kst pieces of 1 KiB, contiguous (pack_conv32_weights); LDS image behind the activation tile
-    const int act_bytes = ((in_px * PST + 1023) >> 10) << 10;
-    const int nwchunk = WC * P.kst * 64;  // 16-B chunks of one stage's weights
+    const int dwb_off = ((in_px * PST + 1023) >> 10) << 10;  // DW: the depthwise-output tile [npix][CK] behind the input tile
+    const int act_bytes = DW ? dwb_off + (((npix * PST + 1023) >> 10) << 10) : dwb_off;
+    const int nwchunk = WC * P.kst * 64 + (DW ? 10 * cpk : 0);  // 16-B chunks of one stage's weights (+ DW: 9 taps + bias of the stage's channels)
+    if constexpr (DW) {
+#pragma unroll
+        for (int mf = 0; mf < MFM; ++mf) pixbase[mf] += dwb_off;
+    }
     const float *wblk = P.wpk + (size_t)cb * P.nstage * nwchunk * 4;
     char *const wlds = smem + act_bytes;
 
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     // staging plan: this thread moves the 16-B chunks idx = tid + k * NT of the [in_px][CK] tile.  Activations come through buffer
     // loads (descriptor in SGPRs, one 32-bit byte offset per chunk): an offset past the descriptor's range reads zeros, which is how
     // the zero padding is written
-    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (VCAT ? 4 : 6) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
-    constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4)
+    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (DW ? 3 : (VCAT ? 4 : 6)) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
+    constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + (DW ? 10 * 8 : 0) + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4; DW: + 10 x CK floats, CK <= 32)
     constexpr unsigned NOPIX = 0xffffffffu;
     const int nchunk = in_px * cpk;
     unsigned goff[IN_U8 ? 1 : MAXLD], goff2[VCAT ? MAXLD : 1];
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         for (int k = 0; k < MAXLD; ++k) {
             const int idx = tid + k * NT;
             int pix, c;
-            if constexpr (KS == 1) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
+            if constexpr (KS == 1 && !DW) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
             else { pix = idx >> P.sh; c = idx & (cpk - 1); }
             const int il = P.NI > 1 ? (int)(((float)pix + 0.5f) * inv_in1) : 0;
             const int pq = pix - il * in_px1;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             for (int k = 0; k < MAXLD; ++k) {
                 const int idx = tid + k * NT;
                 int pix, c;
-                if constexpr (KS == 1) { pix = idx / cpk; c = idx - pix * cpk; }
+                if constexpr (KS == 1 && !DW) { pix = idx / cpk; c = idx - pix * cpk; }
                 else { pix = idx >> P.sh; c = idx & (cpk - 1); }
                 if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + pix * PST + c * 16) = pre[k];
             }
@@ -225,7 +237,30 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         }
         commit();
         __syncthreads();
-        if (stage + 1 < P.nstage) fetch(stage + 1);  // in flight under this stage's MFMAs
+        if constexpr (!DW) { if (stage + 1 < P.nstage) fetch(stage + 1); }  // in flight under this stage's MFMAs
+        if constexpr (DW) {  // depthwise 3x3 + bias + SiLU of this stage's channels: input tile (LDS) -> B-operand tile (LDS)
+            const float *dwl = reinterpret_cast<const float *>(wlds + WC * P.kst * 1024);  // [9 taps + bias][CK]
+            for (int idx = tid; idx < npix * cpk; idx += NT) {
+                const int p = idx >> P.sh, c = idx & (cpk - 1);
+                const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
+                const char *src = smem + (ty * TWin + tx) * PST + c * 16;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+                for (int ky = 0; ky < 3; ++ky)  // (a row of taps at a time: the fully unrolled form held 18 operand vectors and spilled)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + (ky * TWin + kx) * PST);
+                        const float4 wv = *reinterpret_cast<const float4 *>(dwl + (ky * 3 + kx) * P.CK + c * 4);
+                        a0 = fmaf(v.x, wv.x, a0); a1 = fmaf(v.y, wv.y, a1); a2 = fmaf(v.z, wv.z, a2); a3 = fmaf(v.w, wv.w, a3);
+                    }
+                const float4 bvd = *reinterpret_cast<const float4 *>(dwl + 9 * P.CK + c * 4);
+                float4 o = make_float4(a0 + bvd.x, a1 + bvd.y, a2 + bvd.z, a3 + bvd.w);
+                if (P.dw_act) { o.x = silu32(o.x); o.y = silu32(o.y); o.z = silu32(o.z); o.w = silu32(o.w); }
+                *reinterpret_cast<float4 *>(smem + dwb_off + p * PST + c * 16) = o;
+            }
+            __syncthreads();
+            if (stage + 1 < P.nstage) fetch(stage + 1);  // (behind the depthwise phase: its registers are not live across it) in flight under the MFMAs
+        }
         for (int ks = 0; ks < P.kst; ++ks) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(wfrag + ks * 1024);
             int q = ks * 4 + g;
@@ -433,6 +468,44 @@ bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2) {
     return (size_t)16 * (kNW / t.WC) * t.MFM * (cout1 * 4 + 16) <= 80 * 1024;
 }
 
+Conv32Tiling plan_dwpw32(int cin, int cout, int H, int W) {
+    Conv32Tiling t{0, 0, 16, 4, 0, 1};
+    if (cin % 16 || cout % 64 || W > 224) return t;
+    const int WP = kNW / t.WC, maxpix = 16 * WP * c32_mfm_max(t.WC), PST = t.CK * 4 + 16;
+    t.TW = W;
+    int best = 0;
+    int64_t best_cost = -1;
+    for (int th = 1; th <= std::min(H, maxpix / W); ++th) {
+        const int64_t in_px = (int64_t)(th + 2) * (W + 2);
+        const int64_t lds = ((in_px * PST + 1023) & ~1023ll) + (((int64_t)th * W * PST + 1023) & ~1023ll) + t.WC * 1024 + 10 * t.CK * 4;
+        if (lds > 78 * 1024 || in_px * (t.CK / 4) > 3 * kNW * 64) break;
+        const int mfm = std::max(((th * W + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
+        const int64_t cost = (int64_t)((H + th - 1) / th) * (mfm + 1);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = th; }
+    }
+    if (!best) return t;
+    t.TH = best;
+    t.MFM = std::max(((t.TH * W + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
+    return t;
+}
+
+std::vector<float> pack_dwpw32_weights(const float *pw, int cout, int cin, const float *dw_c9, const float *dw_bias, const Conv32Tiling &t) {
+    const int CK = t.CK, nstage = cin / CK, kst = c32_ksteps(1, CK), ncb = cout / (16 * t.WC);
+    const std::vector<float> base = pack_conv32_weights(pw, cout, cin, 1, t, nullptr, false);  // [cb][stage][wc][kst][lane][4]
+    const size_t blk = (size_t)t.WC * kst * 256, dwn = (size_t)10 * CK;
+    std::vector<float> out((size_t)ncb * nstage * (blk + dwn), 0.f);
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int st = 0; st < nstage; ++st) {
+            float *dst = out.data() + ((size_t)cb * nstage + st) * (blk + dwn);
+            std::copy(base.begin() + ((size_t)cb * nstage + st) * blk, base.begin() + ((size_t)cb * nstage + st + 1) * blk, dst);
+            for (int c = 0; c < CK; ++c) {
+                for (int tp = 0; tp < 9; ++tp) dst[blk + (size_t)tp * CK + c] = dw_c9[(size_t)(st * CK + c) * 9 + tp];
+                dst[blk + (size_t)9 * CK + c] = dw_bias[st * CK + c];
+            }
+        }
+    return out;
+}
+
 std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks, const Conv32Tiling &t, const int *perm, bool in_u8) {
     const int CK = t.CK, cpk = CK / 4;
     const int cin_eff = in_u8 ? 4 : cin;
@@ -463,21 +536,28 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
 }
 
 size_t conv32_lds_bytes(const Conv32Launch &L) {
+    if (L.dw) {
+        const size_t PSTd = (size_t)L.CK * 4 + 16;
+        size_t l = (((size_t)(L.TH + 2) * (L.TW + 2) * PSTd + 1023) & ~(size_t)1023) + (((size_t)L.TH * L.TW * PSTd + 1023) & ~(size_t)1023) +
+                   (size_t)L.WC * c32_ksteps(1, L.CK) * 1024 + (size_t)10 * L.CK * 4;
+        if (L.tail_cout > 0) l = std::max(l, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
+        return l;
+    }
     const int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
     size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_ksteps(L.ks, L.CK) * 1024;  // activation tile + stage weights
     if (L.tail_cout > 0) lds = std::max(lds, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
     return lds;
 }
 
-template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL>
+template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false>
 static hipError_t launch32_k(const C32Params &P, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;  // (per instantiation) up to 80 KiB of dynamic LDS: two workgroups per CU
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL>), grid, dim3(kNW * 64), lds, st, P);
+    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>), grid, dim3(kNW * 64), lds, st, P);
     return hipGetLastError();
 }
 
@@ -490,6 +570,13 @@ static hipError_t launch32_f(const Conv32Launch &L, const C32Params &P, int tail
     }
     if (L.up_c > 0) {
         if constexpr (KS == 1 && WC == 4) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0>(P, grid, lds, st); }
+        return hipErrorInvalidValue;
+    }
+    if (L.dw) {
+        if constexpr (KS == 1 && WC == 4) {
+            if (tail_wc2 == 0) return launch32_k<KS, MFM, WC, false, false, 0, true>(P, grid, lds, st);
+            if (tail_wc2 == 1) return launch32_k<KS, MFM, WC, false, false, 1, true>(P, grid, lds, st);
+        }
         return hipErrorInvalidValue;
     }
     switch (tail_wc2) {
@@ -534,7 +621,9 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     const int NI = std::max(1, L.NI);
     if (L.MFM < 1 || L.MFM > c32_mfm_max(L.WC) || NI * L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
     if (NI > 1 && (L.ks != 3 || L.in_u8 || L.up_c || L.tiles_x != 1 || L.tiles_y != 1 || L.TH != L.Hout || L.TW != L.Wout || L.out_hw || L.tail_out_hw)) return hipErrorInvalidValue;
-    P.NI = NI; P.B = L.B;
+    P.NI = NI; P.B = L.B; P.dw_act = L.dw_act;
+    if (L.dw && (L.ks != 1 || L.stride != 1 || L.in_u8 || L.up_c || NI != 1 || L.WC != 4 || L.CK != 16 || L.out_hw || L.tail_out_hw || L.Hin != L.Hout || L.Win != L.Wout || L.TW != L.Wout ||
+                 L.tiles_x != 1)) return hipErrorInvalidValue;
     const int cin_eff = L.in_u8 ? 4 : L.cin;
     if (!L.in_u8 && (L.cin % L.CK || (L.in.cs & 3) || (L.in.co & 3))) return hipErrorInvalidValue;
     if (L.in_u8 && (L.CK != 4 || (L.cin != 3 && L.cin != 4) || !L.lut)) return hipErrorInvalidValue;
@@ -546,7 +635,8 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.ncb = (L.cout + 16 * L.WC - 1) / (16 * L.WC);
     if (ntiles < 1 || (ntiles + 7) / 8 * 8 * P.ncb >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
-    const int TWin = (L.TW - 1) * L.stride + L.ks, THin = (L.TH - 1) * L.stride + L.ks;
+    const int sks = L.dw ? 3 : L.ks;  // staged halo
+    const int TWin = (L.TW - 1) * L.stride + sks, THin = (L.TH - 1) * L.stride + sks;
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
     {
@@ -564,7 +654,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
         if (!L.in_u8 && (span <= 0 || span >= (1ll << 32) - 65536)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = L.in_u8 ? 0u : (unsigned)span;
     }
-    if ((int64_t)NI * THin * TWin * (L.in_u8 ? 1 : L.CK / 4) > (int64_t)(L.up_c > 0 ? 4 : c32_maxld(L.ks, L.in_u8)) * kNW * 64) return hipErrorInvalidValue;  // staging plan: chunks per thread
+    if ((int64_t)NI * THin * TWin * (L.in_u8 ? 1 : L.CK / 4) > (int64_t)(L.dw ? 3 : (L.up_c > 0 ? 4 : c32_maxld(L.ks, L.in_u8))) * kNW * 64) return hipErrorInvalidValue;  // staging plan: chunks per thread
     int tail_wc2 = 0;
     if (L.tail_cout > 0) {
         const Conv32Tiling t{L.TH, L.TW, L.CK, L.WC, L.MFM, NI};

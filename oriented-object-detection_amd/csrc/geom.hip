@@ -1158,36 +1158,36 @@ __global__ __launch_bounds__(64) void k_tile_emit(SurvStage S, const int32_t *__
     }
 }
 
-// Ordered compaction of a merge result: out row r = input row order[i] for the r-th kept sorted position i.  One workgroup walks the
-// sorted positions in chunks of 1024 (ballot + per-wave sums), so the kept rows come out in merge order; *n_out = their number.
-__global__ __launch_bounds__(1024) void k_select_kept(const int32_t *__restrict__ order, const uint8_t *__restrict__ keep, int64_t n,
-                                                     const double *__restrict__ boxes, const int32_t *__restrict__ cls, const double *__restrict__ conf,
-                                                     const double *__restrict__ angle, double *__restrict__ oboxes, int32_t *__restrict__ ocls,
-                                                     double *__restrict__ oconf, double *__restrict__ oangle, int32_t *__restrict__ n_out) {
+// Ordered compaction of a merge result: out row r = input row order[i] for the r-th kept sorted position i.  Three small launches: kept
+// rows per 1024-row block, exclusive scan of the block counts (k_scan_counts, which also leaves the total in *n_out), ordered scatter.
+__global__ __launch_bounds__(1024) void k_kept_count(const uint8_t *__restrict__ keep, int64_t n, int32_t *__restrict__ cnt) {
     __shared__ int wtot[16];
-    __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_s = 0;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    const unsigned long long bal = __ballot(i < n && keep[i]);
+    if (lane == 0) wtot[wave] = __popcll(bal);
     __syncthreads();
-    for (int64_t i0 = 0; i0 < n; i0 += 1024) {
-        const int64_t i = i0 + tid;
-        const bool k = i < n && keep[i];
-        const unsigned long long bal = __ballot(k);
-        if (lane == 0) wtot[wave] = __popcll(bal);
-        __syncthreads();
-        int before = base_s;
-        for (int w = 0; w < wave; ++w) before += wtot[w];
-        if (k) {
-            const int64_t src = order[i], dst = before + __popcll(bal & ((1ull << lane) - 1ull));
-            for (int q = 0; q < 8; ++q) oboxes[dst * 8 + q] = boxes[src * 8 + q];
-            ocls[dst] = cls[src]; oconf[dst] = conf[src];
-            if (angle) oangle[dst] = angle[src];
-        }
-        __syncthreads();
-        if (tid == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wtot[w]; base_s += s; }
-        __syncthreads();
-    }
-    if (tid == 0) *n_out = base_s;
+    if (tid == 0) { int s_ = 0; for (int w = 0; w < 16; ++w) s_ += wtot[w]; cnt[blockIdx.x] = s_; }
+}
+
+__global__ __launch_bounds__(1024) void k_kept_scatter(const int32_t *__restrict__ order, const uint8_t *__restrict__ keep, int64_t n, const int32_t *__restrict__ off,
+                                                      const double *__restrict__ boxes, const int32_t *__restrict__ cls, const double *__restrict__ conf,
+                                                      const double *__restrict__ angle, double *__restrict__ oboxes, int32_t *__restrict__ ocls,
+                                                      double *__restrict__ oconf, double *__restrict__ oangle) {
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    const bool k = i < n && keep[i];
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    if (!k) return;
+    int before = off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    const int64_t src = order[i], dst = before + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int q = 0; q < 8; ++q) oboxes[dst * 8 + q] = boxes[src * 8 + q];
+    ocls[dst] = cls[src]; oconf[dst] = conf[src];
+    if (angle) oangle[dst] = angle[src];
 }
 
 // exchange records -> SoA detections: global float64 corners + strike angle re-derived from the float32 local corners and the integer
@@ -1606,7 +1606,14 @@ int obb_select_kept(obb_ctx *ctx, const int32_t *order, const uint8_t *keep, int
     OBB_REQUIRE(ctx, ctx && n >= 0 && n_out, "obb_select_kept: bad arguments");
     if (n == 0) { OBB_HIP(ctx, hipMemsetAsync(n_out, 0, sizeof(int32_t), (hipStream_t)s)); return OBB_OK; }
     OBB_REQUIRE(ctx, order && keep && boxes && cls && conf && out_boxes && out_cls && out_conf && (!angle || out_angle), "obb_select_kept: NULL buffer");
-    hipLaunchKernelGGL(k_select_kept, dim3(1), dim3(1024), 0, (hipStream_t)s, order, keep, n, boxes, cls, conf, angle, out_boxes, out_cls, out_conf, out_angle, n_out);
+    const int nb = (int)cdiv(n, 1024);
+    int32_t *cnt = (int32_t *)ctx->workspace(WS_SEL, (size_t)(2 * nb + 2) * 4);
+    if (!cnt) return set_error(ctx, OBB_ERR_HIP, "obb_select_kept: workspace allocation failed");
+    int32_t *off = cnt + nb;
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(k_kept_count, dim3((unsigned)nb), dim3(1024), 0, st, keep, n, cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt, nb, off, n_out);
+    hipLaunchKernelGGL(k_kept_scatter, dim3((unsigned)nb), dim3(1024), 0, st, order, keep, n, off, boxes, cls, conf, angle, out_boxes, out_cls, out_conf, out_angle);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

@@ -60,8 +60,9 @@ const char *obb_last_error(const obb_ctx *ctx);
  *     "stem"      model.0 as row stripes on the uint8 tile                             "hmerge"    sibling convs on one input as one launch
  *     "sppf_fuse" the three SPPF pools in one launch                                   "attn_mfma" C2PSA attention on the matrix cores
  *     "front"     model.0 + model.1 + model.2.cv1 as one launch (tile sides % 52 == 0)  "pair"      64 -> 64-cout 3x3 convs on k_conv3_pair
- *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 1..3
- *   concurrent sub-batch chains (default 2), "microbatch" tiles per round (default and maximum 1024). */
+ *     "xtile"     (fp32) conv workgroups stay resident and walk several tiles, the next tile's first stage fetched under this tile's last k loop
+ *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 0..4
+ *   concurrent sub-batch chains (default 0 = 2), "microbatch" tiles per round (default and maximum 1024). */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */

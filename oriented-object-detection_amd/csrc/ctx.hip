@@ -65,7 +65,7 @@ int obb_ctx_create(int device, obb_ctx **out) {
     obb_ctx *c = new obb_ctx();
     c->device = device;
     if (const char *v = getenv("OBB_GRAPH")) c->opt.graph = atoi(v) != 0;  // profiling presets (per-layer kernel traces want eager, one-chain runs)
-    if (const char *v = getenv("OBB_FWD_SPLIT")) c->opt.fwd_split = std::max(1, std::min(3, atoi(v)));
+    if (const char *v = getenv("OBB_FWD_SPLIT")) c->opt.fwd_split = std::max(0, std::min(4, atoi(v)));
     if (const char *v = getenv("OBB_MICROBATCH")) c->opt.microbatch = std::max(1, std::min(1024, atoi(v)));
     *out = c;
     return OBB_OK;

@@ -89,8 +89,9 @@ struct Plan {
     double macs_per_img = 0;
     // hipGraph cache: the ~110 launches of one forward are captured once per (sub-batch size, input pointer, output pointer) and
     // replayed; a key is captured the second time it is seen (the first run is eager: it also performs one-time attribute setup)
-    hipStream_t lanes[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kLanes = 4;
+    hipStream_t lanes[kLanes] = {};
+    hipEvent_t ev_feat[kLanes] = {}, ev_done[kLanes] = {};
     typedef std::tuple<int, const void *, void *> GraphKey;
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> seen;
@@ -103,7 +104,7 @@ struct Plan {
     }
     ~Plan() {
         drop_graphs();
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kLanes; ++i) {
             if (lanes[i]) (void)hipStreamDestroy(lanes[i]);
             if (ev_feat[i]) (void)hipEventDestroy(ev_feat[i]);
             if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
@@ -991,6 +992,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
             case OP_CONV32: {
                 Conv32Launch L = op.c32;
                 L.B = B;
+                L.xtile = M.o.xtile;
                 if (op.in.buf == -1) {
                     L.in.p = (void *)tiles; L.in.bs = (int64_t)P.h * P.w * M.ch; L.in.cs = M.ch; L.in.co = 0;
                 } else if (op.vin) {
@@ -1119,14 +1121,16 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
 // One round (<= max sub-batch) of the forward.  The round is split into `nsplit` independent sub-batches that run concurrently on
 // side streams (fork/join around the caller's stream): the ~110 launches of a forward are a dependent chain of short kernels, and
 // two chains in flight hide each other's ramp-up, tail and launch latency (measured: 4.64 -> 4.26 ms per 256 tiles with 2).
-// Kept at 2 so that caller stream + side streams + one more user stream still fit the 4 hardware queues.
+// "fwd_split" 0 (default) = 2 chains: caller stream + side streams + one more user stream still fit the 4 hardware queues.  (3 / 4
+// chains, 1024-tile bench steps: fp16 8.82 -> 9.86 / 10.58 ms; fp32 within the run-to-run noise of 2 -- 34.99 vs 36.05 on one box,
+// 35.52 vs 35.14 on the next.)
 static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t main_st) {
     Model &M = *ctx->model;
-    const int nsplit_cfg = std::max(1, std::min(3, ctx->opt.fwd_split));
+    const int nsplit_cfg = ctx->opt.fwd_split > 0 ? std::min(Plan::kLanes, ctx->opt.fwd_split) : 2;
     int ns = (B >= 32 * nsplit_cfg) ? nsplit_cfg : 1;
     if (ns == 1) return run_forward(ctx, P, tiles, B, head, main_st, 0);
     if (!P.lanes[0]) {
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < Plan::kLanes; ++i) {
             OBB_HIP(ctx, hipStreamCreateWithFlags(&P.lanes[i], hipStreamNonBlocking));
             OBB_HIP(ctx, hipEventCreateWithFlags(&P.ev_feat[i], hipEventDisableTiming));
             OBB_HIP(ctx, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
@@ -1224,11 +1228,11 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
-        if (k == "fwd_split") { OBB_REQUIRE(ctx, value >= 1 && value <= 3, "obb_set_option: fwd_split must be 1..3"); ctx->opt.fwd_split = (int)value; return OBB_OK; }
+        if (k == "fwd_split") { OBB_REQUIRE(ctx, value >= 0 && value <= 4, "obb_set_option: fwd_split must be 0 (auto) .. 4"); ctx->opt.fwd_split = (int)value; return OBB_OK; }
         if (k == "microbatch") { OBB_REQUIRE(ctx, value >= 1 && value <= 1024, "obb_set_option: microbatch must be 1..1024"); ctx->opt.microbatch = (int)value; return OBB_OK; }
     }
     if (k == "model_slot") {  // several models per context (dual-scale 128 + 416): select which one load/forward address

@@ -40,6 +40,7 @@ struct Conv32Launch {
     int dw = 0, dw_act = 1;  // dw: a depthwise 3x3 (+ bias, SiLU if dw_act) runs in front of this 1x1 inside the launch (wpk from pack_dwpw32_weights)
     int NI = 1;  // > 1: one tile = NI whole images of a small map (TH x TW = the map; the 8 x 8 / 4 x 4 levels of the 128-px scale)
     int tiles_y = 1, tiles_x = 1;
+    int xtile = 1;  // resident workgroups that walk several tiles, the next tile's first stage fetched under this tile's last k loop (plain / VCAT forms)
 };
 
 struct Conv32Tiling { int TH, TW, CK, WC, MFM, NI; };

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace obb {
 
@@ -38,6 +39,8 @@ struct C32Params {
     const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
+    int dbg;    // diagnostic build (-DOBB_DIAG) only: timing ablations, see launch_conv32
+    int tstep;  // > 0: resident workgroups, each walks the tiles t, t + tstep, ... (see XT in k_conv_f32)
     int dw_act;  // DW: SiLU behind the depthwise conv
     int NI, B;  // NI > 1: a tile = NI whole images of a small map (TH x TW = the map), B images in all
     float inv_twin, inv_tw;
@@ -76,8 +79,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     // XCD-aware order (as k_conv_igemm): the cout blocks of one pixel tile are consecutive on one XCD and share the tile through its L2
     const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
     const int cb = lin % P.ncb;
-    const int t = (lin / P.ncb) * 8 + xcd;
+    int t = (lin / P.ncb) * 8 + xcd;
     if (t >= P.ntiles) return;
+    // XT: a workgroup walks the tiles t, t + tstep, ... (tstep > 0: a grid of resident workgroups) and the FIRST stage of the next tile
+    // is fetched under the last k loop of this one and committed to LDS before this tile's epilogue: the fetch latency and the output
+    // stores of a tile, exposed once per tile otherwise (a 1x1 layer has 1-3 stages per tile), overlap the neighbouring tiles' MFMAs.
+    // The fetch registers are dead again before the epilogue starts (committed), so the form costs no registers.  (TAIL / DW / uint8
+    // forms need the LDS tile or further registers in their epilogues and keep one tile per workgroup.)
+    constexpr bool XT = TAIL == 0 && !DW && !IN_U8;
     const int S = P.stride;
     const int THin = (P.TH - 1) * S + SKS, TWin = (P.TW - 1) * S + SKS;
     const int PST = P.CK * 4 + 16;  // bytes per staged pixel (+16 B spreads consecutive pixels over the banks)
@@ -85,18 +94,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     const int nq = (KS == 3 ? 9 : 1) * cpk;
     const int in_px1 = THin * TWin;          // staged pixels of one image
     const int in_px = in_px1 * P.NI;
-    const int tx_i = t % P.tiles_x, r_ = t / P.tiles_x, ty_i = r_ % P.tiles_y;
-    const int b = P.NI > 1 ? t * P.NI : r_ / P.tiles_y;  // (first) image of this tile
-    const int nimg = P.NI > 1 ? min(P.NI, P.B - b) : 1;
-    const int oy0 = ty_i * P.TH, ox0 = tx_i * P.TW;
-    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-    // valid pixels of this tile (edge tiles are clipped): fragments past them are not computed
-    const int vh = min(P.TH, P.Hout - oy0), vw = min(P.TW, P.Wout - ox0);
     const int tpi = P.TH * P.TW;             // output pixels of one image's part of the tile
     const int npix = tpi * P.NI;
-    const int nfrag = ((P.NI > 1 ? nimg * tpi : (vh == P.TH ? tpi : vh * P.TW)) + 15) >> 4;  // whole rows: a clipped tile loses its trailing rows (1-D: TH = 1, all kept)
-    const int nfrag1 = (P.TH == 1) ? ((vw + 15) >> 4) : nfrag;
-    const bool lastv = wp + WP * (MFM - 1) < nfrag1;  // (wave-uniform) the last fragment of this wave exists
     const float inv_tpi = 1.0f / (float)tpi, inv_in1 = 1.0f / (float)in_px1;
 
     int pixbase[MFM];
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
         for (int mf = 0; mf < MFM; ++mf) pixbase[mf] += dwb_off;
     }
-    const float *wblk = P.wpk + (size_t)cb * P.nstage * nwchunk * 4;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(P.wpk + (size_t)cb * P.nstage * nwchunk * 4), 0, P.nstage * nwchunk * 16, 0x00020000);
     char *const wlds = smem + act_bytes;
 
     f32x4 acc[MFM];
@@ -129,46 +128,67 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     // staging plan: this thread moves the 16-B chunks idx = tid + k * NT of the [in_px][CK] tile.  Activations come through buffer
     // loads (descriptor in SGPRs, one 32-bit byte offset per chunk): an offset past the descriptor's range reads zeros, which is how
     // the zero padding is written
-    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (DW ? 3 : (VCAT ? 4 : 6)) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
+    constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (DW ? 3 : (VCAT ? 4 : 7)) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
     constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + (DW ? 10 * 8 : 0) + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4; DW: + 10 x CK floats, CK <= 32)
     constexpr unsigned NOPIX = 0xffffffffu;
     const int nchunk = in_px * cpk;
     unsigned goff[IN_U8 ? 1 : MAXLD], goff2[VCAT ? MAXLD : 1];
     __amdgpu_buffer_rsrc_t in_rsrc, in2_rsrc;
-    if constexpr (!IN_U8) {
-        in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in + (int64_t)b * P.in_bs + P.in_co), 0, (int)P.in_span_bytes, 0x00020000);
-        if constexpr (VCAT) in2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in2 + P.in2_co), 0, (int)P.in2_span_bytes, 0x00020000);
+    if constexpr (VCAT) in2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in2 + P.in2_co), 0, (int)P.in2_span_bytes, 0x00020000);
+    // per-tile (wave-uniform) state: what the k loop and the epilogue of a tile need; `plan` also lays out the tile's fetch offsets
+    struct Tile { int b, nimg, oy0, ox0, nfrag1; bool lastv; };
+    auto plan = [&](int tt, Tile &T) {
+        const int tx_i = tt % P.tiles_x, r_ = tt / P.tiles_x, ty_i = r_ % P.tiles_y;
+        T.b = P.NI > 1 ? tt * P.NI : r_ / P.tiles_y;  // (first) image of this tile
+        T.nimg = P.NI > 1 ? min(P.NI, P.B - T.b) : 1;
+        T.oy0 = ty_i * P.TH; T.ox0 = tx_i * P.TW;
+        const int iy0 = T.oy0 * S - PAD, ix0 = T.ox0 * S - PAD;
+        // valid pixels of this tile (edge tiles are clipped): fragments past them are not computed
+        const int vh = min(P.TH, P.Hout - T.oy0), vw = min(P.TW, P.Wout - T.ox0);
+        const int nfrag = ((P.NI > 1 ? T.nimg * tpi : (vh == P.TH ? tpi : vh * P.TW)) + 15) >> 4;  // whole rows: a clipped tile loses its trailing rows (1-D: TH = 1, all kept)
+        T.nfrag1 = (P.TH == 1) ? ((vw + 15) >> 4) : nfrag;
+        T.lastv = wp + WP * (MFM - 1) < T.nfrag1;  // (wave-uniform) the last fragment of this wave exists
+        if constexpr (!IN_U8) {
+            in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.in + (int64_t)T.b * P.in_bs + P.in_co), 0, (int)P.in_span_bytes, 0x00020000);
+            int tidv = tid;
+            if constexpr (XT) asm volatile("" : "+v"(tidv));  // (opaque: the tile-independent part of the offsets would be hoisted out of the tile loop and held in registers)
 #pragma unroll
-        for (int k = 0; k < MAXLD; ++k) {
-            const int idx = tid + k * NT;
-            int pix, c;
-            if constexpr (KS == 1 && !DW) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
-            else { pix = idx >> P.sh; c = idx & (cpk - 1); }
-            const int il = P.NI > 1 ? (int)(((float)pix + 0.5f) * inv_in1) : 0;
-            const int pq = pix - il * in_px1;
-            const int iy = (int)(((float)pq + 0.5f) * P.inv_twin), ix = pq - iy * TWin;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            const bool ok = idx < nchunk && il < nimg && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
-            if constexpr (VCAT) {  // 1-D: gx = flattened (image, y, x) of the full-resolution level
-                const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
-                const int yy = r / P.up_W, xx = r - yy * P.up_W;
-                const int64_t sp = (int64_t)bb * (P.up_HW >> 2) + (int64_t)(yy >> 1) * (P.up_W >> 1) + (xx >> 1);
-                goff[k] = ok ? (unsigned)((sp * P.in_cs + c * 4) * 4) : NOPIX;
-                goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + c * 4) * 4) : NOPIX;
-            } else {
-                goff[k] = ok ? (unsigned)(((int64_t)il * P.in_bs + ((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+            for (int k = 0; k < MAXLD; ++k) {
+                const int idx = tidv + k * NT;
+                int pix, c;
+                if constexpr (KS == 1 && !DW) { pix = idx / cpk; c = idx - pix * cpk; }  // (1x1: CK may be 48 -- three 16-channel groups in one stage)
+                else { pix = idx >> P.sh; c = idx & (cpk - 1); }
+                const int il = P.NI > 1 ? (int)(((float)pix + 0.5f) * inv_in1) : 0;
+                const int pq = pix - il * in_px1;
+                const int iy = (int)(((float)pq + 0.5f) * P.inv_twin), ix = pq - iy * TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const bool ok = idx < nchunk && il < T.nimg && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+                if constexpr (VCAT) {  // 1-D: gx = flattened (image, y, x) of the full-resolution level
+                    const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
+                    const int yy = r / P.up_W, xx = r - yy * P.up_W;
+                    const int64_t sp = (int64_t)bb * (P.up_HW >> 2) + (int64_t)(yy >> 1) * (P.up_W >> 1) + (xx >> 1);
+                    goff[k] = ok ? (unsigned)((sp * P.in_cs + c * 4) * 4) : NOPIX;
+                    goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + c * 4) * 4) : NOPIX;
+                } else {
+                    goff[k] = ok ? (unsigned)(((int64_t)il * P.in_bs + ((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+                }
             }
         }
-    }
+    };
 
     u32x4 pre[IN_U8 ? 1 : MAXLD];
     f32x4 prew[MAXW];
     auto fetch = [&](int stage) {  // issue the loads of one channel stage (registers `pre`, `prew`)
-        const float *wsrc = wblk + (size_t)stage * nwchunk * 4;
+#ifdef OBB_DIAG
+        if (P.dbg & 1) return;  // timing only: no global fetch (the LDS tile holds whatever it held)
+#endif
+        // (one descriptor + scalar offsets: per-chunk 64-bit addresses would be hoisted out of the loops and held in 2 x MAXW registers)
+        const int wsoff = stage * nwchunk * 16;
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) {
-            const int idx = tid + k * NT;
-            prew[k] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)min(idx, nwchunk - 1) * 4);
+            // (every load unconditional: a load under a branch turns the register into a loop-carried copy, and the copy waits for the load)
+            const int rem = nwchunk - k * NT;  // (wave-uniform) chunks left for this round; none: the round re-reads chunk 0 and is dropped at the commit
+            prew[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, rem > 0 ? min(tid, rem - 1) * 16 : 0, rem > 0 ? wsoff + k * NT * 16 : wsoff, 0));
         }
         if constexpr (!IN_U8) {
             bool second = false;
@@ -195,49 +215,62 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             if (idx < nwchunk) *reinterpret_cast<f32x4 *>(wlds + idx * 16) = prew[k];
         }
         if constexpr (!IN_U8) {
+            int tidc = tid;
+            // (KS 3 x 64 couts, the forms at the register limit: opaque, i.e. the LDS addresses are recomputed per commit -- a few VALU ops per
+            // 250 MFMAs -- instead of living in MAXLD registers across the k loops; the 1x1 forms have the room and 4.5x fewer MFMAs per commit)
+            if constexpr (KS == 3 && WC == 4) asm volatile("" : "+v"(tidc));
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
-                const int idx = tid + k * NT;
+                const int idx = tidc + k * NT;
                 int pix, c;
                 if constexpr (KS == 1 && !DW) { pix = idx / cpk; c = idx - pix * cpk; }
                 else { pix = idx >> P.sh; c = idx & (cpk - 1); }
-                if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + pix * PST + c * 16) = pre[k];
+                if (idx < nchunk) *reinterpret_cast<u32x4 *>(smem + ((pix * PST + c * 16) & ~15)) = pre[k];  // (& ~15: a no-op that keeps the 16-byte alignment visible -> ds_write_b128)
             }
         }
     };
 
+    Tile cur, nxt;
+    plan(t, cur);
     fetch(0);
-    const char *const wfrag = wlds + wc * P.kst * 1024 + lane * 16;
-    for (int stage = 0; stage < P.nstage; ++stage) {
-        if (stage) __syncthreads();  // every wave is done reading the previous stage
-        if constexpr (IN_U8) {  // the uint8 network input: every load of the stage is issued before the first LDS store
-            float4 pv[MAXLD];
-            const uint8_t *src = (const uint8_t *)P.in + (int64_t)b * P.in_bs;
+    if constexpr (IN_U8) {  // the uint8 network input (one stage): every load is issued before the first LDS store
+        float4 pv[MAXLD];
+        const uint8_t *src = (const uint8_t *)P.in + (int64_t)cur.b * P.in_bs;
+        const int iy0 = cur.oy0 * S - PAD, ix0 = cur.ox0 * S - PAD;
 #pragma unroll
-            for (int k = 0; k < MAXLD; ++k) {
-                const int pix = tid + k * NT;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pix < in_px) {
-                    const int iy = (int)(((float)pix + 0.5f) * P.inv_twin), ix = pix - iy * TWin;
-                    const int gy = iy0 + iy, gx = ix0 + ix;
-                    if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
-                        const uint8_t *sp = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
-                        const float c0 = P.lut[sp[0]], c1 = P.lut[sp[1]], c2 = P.lut[sp[2]];
-                        v.x = P.flip_bgr ? c2 : c0; v.y = c1; v.z = P.flip_bgr ? c0 : c2;
-                        if (P.cin == 4) v.w = P.lut[sp[3]];
-                    }
+        for (int k = 0; k < MAXLD; ++k) {
+            const int pix = tid + k * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < in_px) {
+                const int iy = (int)(((float)pix + 0.5f) * P.inv_twin), ix = pix - iy * TWin;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                if (gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win) {
+                    const uint8_t *sp = src + ((int64_t)gy * P.Win + gx) * P.in_cs;
+                    const float c0 = P.lut[sp[0]], c1 = P.lut[sp[1]], c2 = P.lut[sp[2]];
+                    v.x = P.flip_bgr ? c2 : c0; v.y = c1; v.z = P.flip_bgr ? c0 : c2;
+                    if (P.cin == 4) v.w = P.lut[sp[3]];
                 }
-                pv[k] = v;
             }
-#pragma unroll
-            for (int k = 0; k < MAXLD; ++k) {
-                const int pix = tid + k * NT;
-                if (pix < in_px) *reinterpret_cast<float4 *>(smem + pix * PST) = pv[k];
-            }
+            pv[k] = v;
         }
-        commit();
-        __syncthreads();
-        if constexpr (!DW) { if (stage + 1 < P.nstage) fetch(stage + 1); }  // in flight under this stage's MFMAs
+#pragma unroll
+        for (int k = 0; k < MAXLD; ++k) {
+            const int pix = tid + k * NT;
+            if (pix < in_px) *reinterpret_cast<float4 *>(smem + pix * PST) = pv[k];
+        }
+    }
+    commit();
+    __syncthreads();
+    const char *const wfrag = wlds + wc * P.kst * 1024 + lane * 16;
+    const int cbase = F * 16 + g * 4;  // epilogue: lane owns couts [cbase, cbase + 4) of its pixels
+    // (the bias is loaded ONCE, outside the tile loop: a load inside it whose uses sit behind the per-pixel guards stays "pending" for the
+    // compiler on the skipping paths, and the first LDS read of the next k loop that reuses its register then waits vmcnt(0) -- i.e. for
+    // the stage prefetch issued just before)
+    const float4 bv = TAIL > 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(P.bias + cbase);  // bias is padded: always readable
+    for (;;) {
+    bool more = false;  // (XT) the next tile's first stage is in flight / in LDS
+    for (int stage = 0; stage < P.nstage; ++stage) {
+        const bool last = stage + 1 == P.nstage;
         if constexpr (DW) {  // depthwise 3x3 + bias + SiLU of this stage's channels: input tile (LDS) -> B-operand tile (LDS)
             const float *dwl = reinterpret_cast<const float *>(wlds + WC * P.kst * 1024);  // [9 taps + bias][CK]
             for (int idx = tid; idx < npix * cpk; idx += NT) {
@@ -259,8 +292,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                 *reinterpret_cast<float4 *>(smem + dwb_off + p * PST + c * 16) = o;
             }
             __syncthreads();
-            if (stage + 1 < P.nstage) fetch(stage + 1);  // (behind the depthwise phase: its registers are not live across it) in flight under the MFMAs
         }
+        // the next stage (XT: of the next tile) goes in flight under this stage's MFMAs (DW: behind the depthwise phase, whose registers
+        // are then dead)
+        // (ONE fetch site: two of them meet in a phi of the fetch registers, whose copies wait for the loads right behind their issue)
+        int fstage = stage + 1;
+        if constexpr (XT) {
+            if (last && P.tstep > 0 && t + P.tstep < P.ntiles) { plan(t + P.tstep, nxt); fstage = 0; more = true; }
+        }
+        if (!last || more) fetch(fstage);
         for (int ks = 0; ks < P.kst; ++ks) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(wfrag + ks * 1024);
             int q = ks * 4 + g;
@@ -286,14 +326,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
                     for (int i = 0; i < H; ++i) {
                         if (m0 + i < MFM - 1) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[m0 + i], 0, 0, 0);
-                        else if (m0 + i == MFM - 1) { if (lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[MFM - 1], 0, 0, 0); }
+                        else if (m0 + i == MFM - 1) { if (cur.lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[MFM - 1], 0, 0, 0); }
                     }
             }
         }
+        if (!last || more) {
+            __syncthreads();  // every wave is done reading this stage
+            commit();
+            if (!last) __syncthreads();
+        }
     }
 
-    // ---- epilogue: lane owns couts [cbase, cbase + 4) of its pixels
-    const int cbase = F * 16 + g * 4;
+    // ---- epilogue of tile `cur`
     if constexpr (TAIL > 0) {
         // activated tile -> LDS [pixel][cout] (+16 B per row), then the second GEMM over it
         constexpr int WC2 = TAIL, WP2 = NW / WC2, NFR = WP * MFM, MFM2 = (NFR + WP2 - 1) / WP2;
@@ -332,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < MFM2; ++i)
-                    if (wp2 + WP2 * i < nfrag1) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc2[i], 0, 0, 0);
+                    if (wp2 + WP2 * i < cur.nfrag1) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc2[i], 0, 0, 0);
         }
         const int c2 = wc2 * 16 + g * 4;
         if (c2 >= P.cout2) return;
@@ -345,15 +389,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             const int il = P.NI > 1 ? (int)(((float)p + 0.5f) * inv_tpi) : 0;
             const int pq = p - il * tpi;
             const int ty = (int)(((float)pq + 0.5f) * P.inv_tw), tx = pq - ty * P.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            if (oy >= P.Hout || ox >= P.Wout || il >= nimg) continue;
+            const int oy = cur.oy0 + ty, ox = cur.ox0 + tx;
+            if (oy >= P.Hout || ox >= P.Wout || il >= cur.nimg) continue;
             const int64_t opix = (int64_t)oy * P.Wout + ox;
             float v[4] = {acc2[i][0] + bv2.x, acc2[i][1] + bv2.y, acc2[i][2] + bv2.z, acc2[i][3] + bv2.w};
             if (P.act2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
             }
-            int64_t ob = b + il, opx = opix;
+            int64_t ob = cur.b + il, opx = opix;
             if (P.out2_hw > 0) { ob = opx / P.out2_hw; opx -= ob * P.out2_hw; }
             float *op = P.out2 + ob * P.out2_bs + opx * P.out2_cs + P.out2_co + c2;
             if (full2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
@@ -366,18 +410,21 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         }
         return;
     }
-    if (cbase >= P.cout) return;
-    const float4 bv = *reinterpret_cast<const float4 *>(P.bias + cbase);  // bias is padded: always readable
+#ifdef OBB_DIAG
+    if (P.dbg & 2) { if (acc[0][0] != 123.456f) return; }  // timing only: no epilogue (the test keeps the accumulators alive)
+#endif
+    int plv = pl;
+    if constexpr (XT) asm volatile("" : "+v"(plv));  // (opaque, as in `plan`: the pixel coordinates are recomputed per tile, not kept across the k loops)
     const bool full = cbase + 4 <= P.cout;
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) {
-        const int p = (wp + WP * mf) * 16 + pl;
-        if (p >= npix) continue;
+        const int p = (wp + WP * mf) * 16 + plv;
+        if (p >= npix || cbase >= P.cout) continue;
         const int il = P.NI > 1 ? (int)(((float)p + 0.5f) * inv_tpi) : 0;
         const int pq = p - il * tpi;
         const int ty = (int)(((float)pq + 0.5f) * P.inv_tw), tx = pq - ty * P.TW;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        if (oy >= P.Hout || ox >= P.Wout || il >= nimg) continue;
+        const int oy = cur.oy0 + ty, ox = cur.ox0 + tx;
+        if (oy >= P.Hout || ox >= P.Wout || il >= cur.nimg) continue;
         const int64_t opix = (int64_t)oy * P.Wout + ox;
         float v[4] = {acc[mf][0] + bv.x, acc[mf][1] + bv.y, acc[mf][2] + bv.z, acc[mf][3] + bv.w};
         if (P.act) {
@@ -385,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
         }
         if (P.res) {
-            const float *rp = P.res + (int64_t)(b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase;
+            const float *rp = P.res + (int64_t)(cur.b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase;
             if (full) {
                 const float4 rv = *reinterpret_cast<const float4 *>(rp);
                 v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                     if (cbase + j < P.cout) v[j] = rp[j] + v[j];
             }
         }
-        int64_t ob = b + il, opx = opix;
+        int64_t ob = cur.b + il, opx = opix;
         if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }
         float *op = P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
         if (full && ((P.out_cs | P.out_co) & 3) == 0) {
@@ -406,6 +453,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                 if (cbase + j < P.cout) op[j] = v[j];
         }
     }
+    if constexpr (!XT) return;
+    if (!more) return;
+    __syncthreads();  // the next tile's first stage is in LDS
+    t += P.tstep;
+    cur = nxt;
+#pragma unroll
+    for (int mf = 0; mf < MFM; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -414,14 +469,15 @@ static int ilog2_(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 static int c32_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 4) + 3) / 4; }
 static int c32_mfm_max(int WC) { return WC == 4 ? 7 : (WC == 2 ? 4 : 2); }  // 224 / 256 / 256 pixels per tile
 static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
-static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 6 : 5); }
+static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
 
 Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat) {
     Conv32Tiling t;
     t.WC = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
     if (in_u8) t.CK = 4;
     else {
-        const int cap = ks == 1 ? 32 : (stride == 2 ? 8 : 16);  // (1x1 with 64-channel stages: measured, no gain -- 18.05 -> 18.22 ms per 512 tiles)
+        // (1x1: 64-channel stages = half the barriers and LDS commits of 32: 18.40 -> 18.27 ms per 512 tiles, the 13 x 13 layers 4-6 %)
+        const int cap = ks == 1 ? (vcat ? 32 : 64) : (stride == 2 ? 8 : 16);  // (1x1 with 64-channel stages: measured, no gain -- 18.05 -> 18.22 ms per 512 tiles)
         int ck = 4;
         while (ck * 2 <= cap && cin % (ck * 2) == 0) ck *= 2;
         if (ks == 1 && !vcat && ck == 16 && cin % 48 == 0) ck = 48;  // 48- / 96-channel concats: one stage of three 16-channel groups instead of three stages of one k step
@@ -550,12 +606,40 @@ size_t conv32_lds_bytes(const Conv32Launch &L) {
 }
 
 template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false>
-static hipError_t launch32_k(const C32Params &P, dim3 grid, size_t lds, hipStream_t st) {
+static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStream_t st) {
+    const void *fn = (const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>;
     static bool attr_set = false;  // (per instantiation) up to 80 KiB of dynamic LDS: two workgroups per CU
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    C32Params P = P0;
+    P.tstep = 0;
+    // (measured per layer, 512 tiles: layers of 1-3 stages per tile gain 3-18 % -- model.2.cv2 867 -> 707 us -- longer tiles hide their
+    // first fetch and their stores behind the co-resident workgroup anyway and only lose to the coarser tile split)
+    if (TAIL == 0 && !DW && !IN_U8 && P0.tstep != 0 && P0.nstage <= 3) {  // (launch_conv32 passes Conv32Launch::xtile in tstep)
+        // cross-tile pipeline: a grid of resident workgroups, each walking ~equally many tiles (see XT in the kernel)
+        static std::map<size_t, int> occ;  // resident workgroups per CU of this instantiation, by dynamic LDS size
+        static int ncu = 0;
+        auto it = occ.find(lds);
+        if (it == occ.end()) {
+            int n = 0, dev = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kNW * 64, lds);
+            if (e != hipSuccess) return e;
+            if (!ncu) {
+                if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            }
+            it = occ.emplace(lds, std::max(1, n)).first;
+        }
+        const int64_t tiles8 = ((int64_t)P.ntiles + 7) / 8;
+        const int64_t slots_max = std::max<int64_t>(1, (int64_t)it->second * ncu / (8 * P.ncb));
+        const int64_t rounds = (tiles8 + slots_max - 1) / slots_max;
+        if (rounds > 1) {
+            const int64_t slots = (tiles8 + rounds - 1) / rounds;
+            P.tstep = (int)(slots * 8);
+            grid = dim3((unsigned)(slots * 8 * P.ncb));
+        }
     }
     hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>), grid, dim3(kNW * 64), lds, st, P);
     return hipGetLastError();
@@ -665,6 +749,10 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
         P.w2 = L.tail_w; P.b2 = L.tail_b; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs; P.out2_co = L.tail_out.co;
         P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.act2 = L.tail_act; P.kst2 = L.cout / 16;
     }
+    P.tstep = L.xtile ? 1 : 0;
+#ifdef OBB_DIAG
+    { static const int dbg = getenv("OBB_C32_DBG") ? atoi(getenv("OBB_C32_DBG")) : 0; P.dbg = dbg; }  // 1: no global fetch, 2: no epilogue (timing-only ablations)
+#endif
     const size_t lds = conv32_lds_bytes(L);
     if (lds > 80 * 1024 || P.kst > (L.ks == 3 ? 9 : 4)) return hipErrorInvalidValue;  // (kst bound: the weight-fetch plan of the kernel, MAXW)
     dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * P.ncb));

@@ -76,7 +76,7 @@ class YOLO:
                        detections of a dense scene match the fp32 pipeline (IoU >= 0.5, |d conf| <= 0.12), not all of them.
       "bf16"           like "f16" with bf16 storage: 8 significand bits, ~78 % agreement; only for experiments."""
 
-    def __init__(self, weights, imgsz=416, device=None, precision="f32", names=None):
+    def __init__(self, weights, imgsz=416, device=None, precision="f32", names=None, engine_options=None):
         if not torch.cuda.is_available():
             raise RuntimeError("YOLO: no HIP device visible; this implementation has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
@@ -91,6 +91,7 @@ class YOLO:
                 blob = f.read()
         self._blob = blob
         self.precision = precision
+        self.engine_options = dict(engine_options or {})  # ops.MODEL_OPTIONS switches (A/B measurements and parity tests; all default on)
         self.imgsz = int(imgsz)
         self.names = names or {}
         self._load()
@@ -108,7 +109,7 @@ class YOLO:
             YOLO._next_slot[idx] = self._slot + 1
         with torch.cuda.device(self.device):
             ops.select_model(self._slot, self.device)
-            ops.model_load(self._blob, self.device, self.precision)
+            ops.model_load(self._blob, self.device, self.precision, **self.engine_options)
             info = ops.model_info(self.imgsz, self.imgsz, self.device)
         self.nc, self.ch = info["nc"], info["ch"]
 

@@ -105,6 +105,20 @@ def test_fp32_fused_forms_are_bit_identical(ood, nets, h, w, B):
     assert float(d0.max()) < 2e-6 * max(1.0, float(x0_plain.abs().max())) and float(d.max()) < 5e-4 and float(d.mean()) < 3e-5
 
 
+@pytest.mark.parametrize("h,w,B", [(416, 416, 40), (128, 128, 600), (192, 416, 37)])
+def test_fp32_resident_workgroups_are_bit_identical(ood, nets, h, w, B):
+    """`xtile`: conv workgroups that stay resident and walk several tiles (next tile's first stage fetched under this tile's last k loop)
+    against one tile per workgroup -- the same arithmetic in the same order, so the heads must agree BIT FOR BIT.  The batch is large
+    enough for more tiles than resident workgroups in most layers (a small batch never takes the resident form)."""
+    ops, net = ood.ops, nets[416]
+    x = torch.as_tensor(_tiles(7 + h, B, h, w)).cuda()
+    ops.model_load(net.to_blob(), precision="f32", xtile=False)
+    one = ops.forward(x).cpu()
+    ops.model_load(net.to_blob(), precision="f32")
+    res = ops.forward(x).cpu()
+    assert torch.equal(one[..., :77], res[..., :77]), float((one - res)[..., :77].abs().max())
+
+
 @pytest.mark.parametrize("h,w,B,ch", [(416, 416, 3, 3), (128, 128, 5, 3), (416, 288, 2, 3), (192, 416, 2, 3), (64, 96, 3, 3), (416, 416, 2, 4)])
 def test_fp32_head_matches_fp32_oracle(ood, nets, h, w, B, ch):
     ops = ood.ops

@@ -32,7 +32,8 @@ else:
     out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/layers"
     os.makedirs(out, exist_ok=True)
     S = int(os.environ.get("OBB_SIZE", "416"))  # tile side (the 128-px scale of the dual-scale config: OBB_SIZE=128, weights of seed 1)
-    m = YOLO(make_weights.ensure("n", 12, 3, 0 if S == 416 else 1), imgsz=S, precision=os.environ.get("OBB_PREC", "f16"))
+    m = YOLO(make_weights.ensure("n", 12, 3, 0 if S == 416 else 1), imgsz=S, precision=os.environ.get("OBB_PREC", "f16"),
+             engine_options={k: bool(int(v)) for k, v in (kv.split("=") for kv in os.environ.get("OBB_OPTS", "").split(",") if kv)})  # e.g. OBB_OPTS=xtile=0
     open(out + "/plan.txt", "w").write("\n".join(ops.debug_plan(S, S)))
     open(out + "/B.txt", "w").write(str(B))
     tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, S, S, 3), dtype=np.uint8)).cuda()

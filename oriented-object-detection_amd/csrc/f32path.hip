@@ -39,6 +39,7 @@ struct C32Params {
     const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
+    int krem, wcb;  // 4-channel chunks of a stage beyond the kst whole pieces (0..3: one MFMA each); bytes of one cout fragment's stage weights
     int dbg;    // diagnostic build (-DOBB_DIAG) only: timing ablations, see launch_conv32
     int tstep;  // > 0: resident workgroups, each walks the tiles t, t + tstep, ... (see XT in k_conv_f32)
     int dw_act;  // DW: SiLU behind the depthwise conv
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     // weights of (cout block cb, stage): WC * kst pieces of 1 KiB, contiguous (pack_conv32_weights); LDS image behind the activation tile
     const int dwb_off = ((in_px * PST + 1023) >> 10) << 10;  // DW: the depthwise-output tile [npix][CK] behind the input tile
     const int act_bytes = DW ? dwb_off + (((npix * PST + 1023) >> 10) << 10) : dwb_off;
-    const int nwchunk = WC * P.kst * 64 + (DW ? 10 * cpk : 0);  // 16-B chunks of one stage's weights (+ DW: 9 taps + bias of the stage's channels)
+    const int nwchunk = WC * (P.wcb >> 4) + (DW ? 10 * cpk : 0);  // 16-B chunks of one stage's weights (+ DW: 9 taps + bias of the stage's channels)
     if constexpr (DW) {
 #pragma unroll
         for (int mf = 0; mf < MFM; ++mf) pixbase[mf] += dwb_off;
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     }
     commit();
     __syncthreads();
-    const char *const wfrag = wlds + wc * P.kst * 1024 + lane * 16;
+    const char *const wfrag = wlds + wc * P.wcb + lane * 16;
+    const char *const wrem = wlds + wc * P.wcb + P.kst * 1024 + lane * 4;  // the remainder chunks' weights: [chunk][lane] floats
     const int cbase = F * 16 + g * 4;  // epilogue: lane owns couts [cbase, cbase + 4) of its pixels
     // (the bias is loaded ONCE, outside the tile loop: a load inside it whose uses sit behind the per-pixel guards stays "pending" for the
     // compiler on the skipping paths, and the first LDS read of the next k loop that reuses its register then waits vmcnt(0) -- i.e. for
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     for (int stage = 0; stage < P.nstage; ++stage) {
         const bool last = stage + 1 == P.nstage;
         if constexpr (DW) {  // depthwise 3x3 + bias + SiLU of this stage's channels: input tile (LDS) -> B-operand tile (LDS)
-            const float *dwl = reinterpret_cast<const float *>(wlds + WC * P.kst * 1024);  // [9 taps + bias][CK]
+            const float *dwl = reinterpret_cast<const float *>(wlds + WC * P.wcb);  // [9 taps + bias][CK]
             for (int idx = tid; idx < npix * cpk; idx += NT) {
                 const int p = idx >> P.sh, c = idx & (cpk - 1);
                 const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         for (int ks = 0; ks < P.kst; ++ks) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(wfrag + ks * 1024);
             int q = ks * 4 + g;
-            q = q < nq ? q : nq - 1;  // padding chunks: any valid address, their weights are zero
+            if constexpr (KS == 1) q = q < nq ? q : nq - 1;  // (1x1: the last piece may be padded -- any valid address, its weights are zero)
             int off;
             if constexpr (KS == 3) {
                 const int tap = q >> P.sh, c0 = q & (cpk - 1);
@@ -328,6 +330,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                         if (m0 + i < MFM - 1) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[m0 + i], 0, 0, 0);
                         else if (m0 + i == MFM - 1) { if (cur.lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[MFM - 1], 0, 0, 0); }
                     }
+            }
+        }
+        // the stage's last nq % 4 chunks, ONE MFMA each: the four k slots of the instruction are the chunk's four channels (lane group g
+        // reads channel g: ds_read_b32) -- a 3x3 stage of 8 channels is 18 chunks = 4 pieces + 2 of these = 18 MFMAs per fragment, where
+        // padding the stage to 5 pieces cost 20
+        if constexpr (KS == 3)
+        for (int r = 0; r < P.krem; ++r) {
+            const float w1 = *reinterpret_cast<const float *>(wrem + r * 256);
+            const int q = P.kst * 4 + r;
+            const int tap = q >> P.sh, c0 = q & (cpk - 1);
+            const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+            const int off = (dy * TWin + dx) * PST + c0 * 16 + g * 4;
+            float a1[MFM];
+#pragma unroll
+            for (int mf = 0; mf < MFM; ++mf) a1[mf] = *reinterpret_cast<const float *>(smem + pixbase[mf] + off);
+#pragma unroll
+            for (int mf = 0; mf < MFM; ++mf) {
+                if (mf < MFM - 1) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[mf], acc[mf], 0, 0, 0);
+                else if (cur.lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[mf], acc[MFM - 1], 0, 0, 0);
             }
         }
         if (!last || more) {
@@ -466,7 +487,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 // ------------------------------------------------------------------------------------------------ host side
 static constexpr int kNW = 8;  // waves per workgroup
 static int ilog2_(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
-static int c32_ksteps(int ks, int CK) { return ((ks == 3 ? 9 : 1) * (CK / 4) + 3) / 4; }
+// a stage's k = taps x CK channels in 4-channel chunks: kfull pieces of 4 chunks (four MFMAs behind one ds_read_b128 per operand) + krem
+// single chunks (one MFMA each); wfloats = weights of one cout fragment and stage
+// (1x1: whole pieces only, the last one zero-padded -- no 1x1 layer of the network has fewer than 16 input channels, and the remainder
+// loop's registers are what the 1x1 forms at 7 fragments per wave do not have)
+static int c32_kfull(int ks, int CK) { return ks == 3 ? (9 * (CK / 4)) / 4 : (CK / 4 + 3) / 4; }
+static int c32_krem(int ks, int CK) { return ks == 3 ? (9 * (CK / 4)) % 4 : 0; }
+static int c32_wfloats(int ks, int CK) { return c32_kfull(ks, CK) * 256 + c32_krem(ks, CK) * 64; }
 static int c32_mfm_max(int WC) { return WC == 4 ? 7 : (WC == 2 ? 4 : 2); }  // 224 / 256 / 256 pixels per tile
 static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
 static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
@@ -487,7 +514,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     const int maxpix = 16 * WP * MFMX;
     const int chunk_cap = (vcat ? 4 : c32_maxld(ks, in_u8)) * kNW * 64;  // 16-B chunks one stage may hold
     if (ks == 1) {  // 1-D: the caller flattens batch x pixels
-        while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * c32_ksteps(1, t.CK) * 1024 > 78 * 1024)) t.CK /= 2;
+        while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * c32_wfloats(1, t.CK) * 4 > 78 * 1024)) t.CK /= 2;
         t.TH = 1; t.TW = maxpix; t.MFM = MFMX; t.NI = 1;
         return t;
     }
@@ -498,7 +525,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     int64_t best_cost = -1;
     for (int th = 1; th <= std::min(Hout, maxpix / t.TW); ++th) {
         const int64_t in_px = (int64_t)((th - 1) * stride + ks) * ((t.TW - 1) * stride + ks);
-        if (in_px * PST + t.WC * c32_ksteps(ks, t.CK) * 1024 > 78 * 1024 || in_px * (in_u8 ? 1 : t.CK / 4) > chunk_cap) break;
+        if (in_px * PST + t.WC * c32_wfloats(ks, t.CK) * 4 > 78 * 1024 || in_px * (in_u8 ? 1 : t.CK / 4) > chunk_cap) break;
         // time ~ tiles x (fragments of the busiest wave + the fixed cost of a stage: barriers + LDS commit, about one fragment's MFMAs)
         const int mfm = std::max(((th * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
         const int64_t cost = (int64_t)((Hout + th - 1) / th) * tiles_x * (mfm + 1);
@@ -511,7 +538,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
         // tile and the staging plan take -- a tile of ONE such map would leave most of the workgroup's fragments empty
         const int64_t in1 = (int64_t)((Hout - 1) * stride + ks) * ((Wout - 1) * stride + ks);
         int ni = maxpix / (Hout * Wout);
-        while (ni > 1 && (ni * in1 * PST + t.WC * c32_ksteps(ks, t.CK) * 1024 > 78 * 1024 || ni * in1 * (t.CK / 4) > chunk_cap)) --ni;
+        while (ni > 1 && (ni * in1 * PST + t.WC * c32_wfloats(ks, t.CK) * 4 > 78 * 1024 || ni * in1 * (t.CK / 4) > chunk_cap)) --ni;
         t.NI = ni;
     }
     t.MFM = std::max(((t.NI * t.TH * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
@@ -546,9 +573,9 @@ Conv32Tiling plan_dwpw32(int cin, int cout, int H, int W) {
 }
 
 std::vector<float> pack_dwpw32_weights(const float *pw, int cout, int cin, const float *dw_c9, const float *dw_bias, const Conv32Tiling &t) {
-    const int CK = t.CK, nstage = cin / CK, kst = c32_ksteps(1, CK), ncb = cout / (16 * t.WC);
+    const int CK = t.CK, nstage = cin / CK, ncb = cout / (16 * t.WC);
     const std::vector<float> base = pack_conv32_weights(pw, cout, cin, 1, t, nullptr, false);  // [cb][stage][wc][kst][lane][4]
-    const size_t blk = (size_t)t.WC * kst * 256, dwn = (size_t)10 * CK;
+    const size_t blk = (size_t)t.WC * c32_wfloats(1, CK), dwn = (size_t)10 * CK;
     std::vector<float> out((size_t)ncb * nstage * (blk + dwn), 0.f);
     for (int cb = 0; cb < ncb; ++cb)
         for (int st = 0; st < nstage; ++st) {
@@ -566,28 +593,27 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
     const int CK = t.CK, cpk = CK / 4;
     const int cin_eff = in_u8 ? 4 : cin;
     const int nstage = (cin_eff + CK - 1) / CK;
-    const int kst = c32_ksteps(ks, CK);
+    const int kst = c32_kfull(ks, CK), krem = c32_krem(ks, CK);
     const int nf = (cout + 15) / 16;
     const int nfp = (nf + t.WC - 1) / t.WC * t.WC;  // whole cout blocks
-    const int taps = ks * ks, nq = taps * cpk;
-    std::vector<float> out((size_t)nfp * nstage * kst * 256, 0.f);
+    const int taps = ks * ks;
+    std::vector<float> out((size_t)nfp * nstage * c32_wfloats(ks, CK), 0.f);
     size_t o = 0;
-    for (int cb = 0; cb < nfp / t.WC; ++cb)  // [cout block][stage][fragment of the block][k step][lane][4]: a workgroup's stage is one contiguous run
+    auto wat = [&](int co, int st, int q, int s) -> float {  // weight of cout co for channel s of the stage's chunk q
+        const int tap = q / cpk, c = st * CK + (q % cpk) * 4 + s;
+        if (co >= cout || c >= cin || q >= taps * cpk) return 0.f;
+        return w[((size_t)(perm ? perm[co] : co) * cin + c) * taps + tap];
+    };
+    // [cout block][stage][fragment of the block]{[piece][lane][4], [remainder chunk][lane]}: a workgroup's stage is one contiguous run
+    for (int cb = 0; cb < nfp / t.WC; ++cb)
         for (int st = 0; st < nstage; ++st)
-            for (int wc = 0; wc < t.WC; ++wc)
+            for (int wc = 0; wc < t.WC; ++wc) {
                 for (int k = 0; k < kst; ++k)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int r = lane & 15, gq = lane >> 4;
-                        const int co = (cb * t.WC + wc) * 16 + r;
-                        const int q = k * 4 + gq;
-                        for (int s = 0; s < 4; ++s, ++o) {
-                            if (q >= nq || co >= cout) continue;
-                            const int tap = q / cpk, c = st * CK + (q % cpk) * 4 + s;
-                            if (c >= cin) continue;
-                            const int src = perm ? perm[co] : co;
-                            out[o] = w[((size_t)src * cin + c) * taps + tap];
-                        }
-                    }
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s) out[o++] = wat((cb * t.WC + wc) * 16 + (lane & 15), st, k * 4 + (lane >> 4), s);
+                for (int r = 0; r < krem; ++r)
+                    for (int lane = 0; lane < 64; ++lane) out[o++] = wat((cb * t.WC + wc) * 16 + (lane & 15), st, kst * 4 + r, lane >> 4);
+            }
     return out;
 }
 
@@ -595,12 +621,12 @@ size_t conv32_lds_bytes(const Conv32Launch &L) {
     if (L.dw) {
         const size_t PSTd = (size_t)L.CK * 4 + 16;
         size_t l = (((size_t)(L.TH + 2) * (L.TW + 2) * PSTd + 1023) & ~(size_t)1023) + (((size_t)L.TH * L.TW * PSTd + 1023) & ~(size_t)1023) +
-                   (size_t)L.WC * c32_ksteps(1, L.CK) * 1024 + (size_t)10 * L.CK * 4;
+                   (size_t)L.WC * c32_wfloats(1, L.CK) * 4 + (size_t)10 * L.CK * 4;
         if (L.tail_cout > 0) l = std::max(l, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
         return l;
     }
     const int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_ksteps(L.ks, L.CK) * 1024;  // activation tile + stage weights
+    size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_wfloats(L.ks, L.CK) * 4;  // activation tile + stage weights
     if (L.tail_cout > 0) lds = std::max(lds, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
     return lds;
 }
@@ -713,7 +739,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     if (L.in_u8 && (L.CK != 4 || (L.cin != 3 && L.cin != 4) || !L.lut)) return hipErrorInvalidValue;
     if (L.res.p && ((L.res.cs | L.res.co) & 3)) return hipErrorInvalidValue;
     P.nstage = (cin_eff + L.CK - 1) / L.CK;
-    P.kst = c32_ksteps(L.ks, L.CK);
+    P.kst = c32_kfull(L.ks, L.CK); P.krem = c32_krem(L.ks, L.CK); P.wcb = c32_wfloats(L.ks, L.CK) * 4;
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw;
     const int64_t ntiles = NI > 1 ? ((int64_t)L.B + NI - 1) / NI : (int64_t)L.B * L.tiles_y * L.tiles_x;
     P.ncb = (L.cout + 16 * L.WC - 1) / (16 * L.WC);

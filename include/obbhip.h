@@ -62,7 +62,8 @@ const char *obb_last_error(const obb_ctx *ctx);
  *     "front"     model.0 + model.1 + model.2.cv1 as one launch (tile sides % 52 == 0)  "pair"      64 -> 64-cout 3x3 convs on k_conv3_pair
  *     "xtile"     (fp32) conv workgroups stay resident and walk several tiles, the next tile's first stage fetched under this tile's last k loop
  *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 0..4
- *   concurrent sub-batch chains (default 0 = 2), "microbatch" tiles per round (default and maximum 1024). */
+ *   concurrent sub-batch chains (default 0 = 2), "microbatch" 416 x 416 tiles per round (default and maximum 1024; smaller tiles
+ *   get proportionally more per round, at most 8192: 128 px -> 8192). */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */

@@ -1269,7 +1269,10 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
     int rc = get_plan(ctx, h, w, &P);
     if (rc) return rc;
     // The batch is walked in sub-batches: bounds the activation slab (and keeps every 1-D launch inside 32-bit buffer offsets)
-    const int max_mb = ctx->opt.microbatch;  // measured at B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s (128 / 256: 67 / 79 k with the round-1 kernels)
+    // "microbatch" counts 416 x 416 tiles: smaller tiles get proportionally more per round (128 px: 8192) -- the same activation bytes and
+    // launch sizes, instead of 1024-tile rounds whose 4 x 4 / 8 x 8 levels are 74-WG launches on a 256-CU chip.  (measured at 416 px,
+    // B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s; 128 / 256: 67 / 79 k with the round-1 kernels)
+    const int max_mb = (int)std::min<int64_t>(8192, (int64_t)ctx->opt.microbatch * std::max<int64_t>(1, (416 * 416) / ((int64_t)h * w)));
     rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
     bool use_graph = ctx->opt.graph;

@@ -566,7 +566,9 @@ Conv32Tiling plan_dwpw32(int cin, int cout, int H, int W) {
         const int64_t cost = (int64_t)((H + th - 1) / th) * (mfm + 1);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = th; }
     }
-    if (!best) return t;
+    // (a tile is whole rows of ONE image: the 8 x 8 / 4 x 4 maps of the 128-px scale would fill 64 / 16 of a workgroup's >= 128 pixel slots
+    // -- measured 8192 tiles: 452 us at 10.8 TFLOP/s for the 4 x 4 pair -- and keep their separate depthwise + flattened 1x1 launches)
+    if (!best || best * W < 112) return t;
     t.TH = best;
     t.MFM = std::max(((t.TH * W + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
     return t;

@@ -22,8 +22,8 @@ cp(O + "/prof_f16/*/*_kernel_stats.csv", "bench_f16_kernel_stats_sequential.csv"
 cp(O + "/layers32.txt", "forward_f32_layers_b256.txt")
 cp(O + "/layers32_512.txt", "forward_f32_layers_b512.txt")
 cp(O + "/layers.txt", "forward_f16_layers_b256.txt")
-cp(O + "/layers32_128.txt", "forward_f32_layers_128px_b1024.txt")
-cp(O + "/layers_128.txt", "forward_f16_layers_128px_b1024.txt")
+cp(O + "/layers32_128.txt", "forward_f32_layers_128px_b8192.txt")
+cp(O + "/layers_128.txt", "forward_f16_layers_128px_b8192.txt")
 cp(O + "/postproc.txt", "postproc.txt")
 cp(O + "/merge_scaling.txt", "merge_scaling.txt")
 cp(O + "/pptrace/*/*_kernel_stats.csv", "decode_nms_kernel_stats.csv")

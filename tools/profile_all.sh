@@ -13,15 +13,15 @@ python3 bench.py --no-cpu-baseline --no-extras --no-pipeline > $O/bench_nopipe.j
 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32 -- $LP 256 $O/layers32 > $O/layers32.log 2>&1 && $LP report $O/layers32 > $O/layers32.txt
 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_512 -- $LP 512 $O/layers32_512 > $O/layers32_512.log 2>&1 && $LP report $O/layers32_512 > $O/layers32_512.txt
 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers -- $LP 256 $O/layers > $O/layers.log 2>&1 && $LP report $O/layers > $O/layers.txt
-OBB_SIZE=128 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_128 -- $LP 2048 $O/layers32_128 > $O/layers32_128.log 2>&1 && $LP report $O/layers32_128 > $O/layers32_128.txt
-OBB_SIZE=128 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers_128 -- $LP 2048 $O/layers_128 > $O/layers_128.log 2>&1 && $LP report $O/layers_128 > $O/layers_128.txt
+OBB_SIZE=128 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_128 -- $LP 8192 $O/layers32_128 > $O/layers32_128.log 2>&1 && $LP report $O/layers32_128 > $O/layers32_128.txt
+OBB_SIZE=128 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers_128 -- $LP 8192 $O/layers_128 > $O/layers_128.log 2>&1 && $LP report $O/layers_128 > $O/layers_128.txt
 fi
 if [ "${PART:-a}" = a32 ]; then  # the fp32 subset of part a (after a change of the fp32 kernels only)
 python3 bench.py > $O/bench.json 2> $O/bench.err
 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 bench.py --no-cpu-baseline --no-extras --no-pipeline --steps 8 > $O/bench_prof_f32.log 2>&1
 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32 -- $LP 256 $O/layers32 > $O/layers32.log 2>&1 && $LP report $O/layers32 > $O/layers32.txt
 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_512 -- $LP 512 $O/layers32_512 > $O/layers32_512.log 2>&1 && $LP report $O/layers32_512 > $O/layers32_512.txt
-OBB_SIZE=128 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_128 -- $LP 2048 $O/layers32_128 > $O/layers32_128.log 2>&1 && $LP report $O/layers32_128 > $O/layers32_128.txt
+OBB_SIZE=128 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/layers32_128 -- $LP 8192 $O/layers32_128 > $O/layers32_128.log 2>&1 && $LP report $O/layers32_128 > $O/layers32_128.txt
 fi
 if [ "${PART:-a}" = b ]; then
 OBB_PREC=f32 OBB_GRAPH=0 OBB_FWD_SPLIT=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- $LP 256 $O/pmc_fetch32 > $O/pmc_fetch32.log 2>&1

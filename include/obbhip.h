@@ -246,6 +246,15 @@ int obb_dfl_loss(obb_ctx *ctx, const float *pred_dist, const float *target_ltrb,
 int obb_bce_loss(obb_ctx *ctx, const float *logits, const float *targets, int64_t n, float target_scores_sum, float *loss, float *grad_logits,
                  obb_stream_t s);
 
+/* f1 (optimiser step): the update behind `model.train(...)` (Train_OBB.py:796-841; ultralytics `build_optimizer`: torch.optim.SGD with
+ * nesterov momentum or torch.optim.AdamW, three parameter groups).  A group = flat fp32 device buffers of n elements, 16-byte aligned.
+ * obb_sgd_step: d = grad + weight_decay * param; buf = first_step ? d : momentum * buf + d; d = nesterov ? d + momentum * buf : buf;
+ * param -= lr * d (momentum 0: no buffer touched).  obb_adamw_step: torch.optim.AdamW's single-tensor order with step counted from 1. */
+int obb_sgd_step(obb_ctx *ctx, float *param, const float *grad, float *momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                 int32_t nesterov, int32_t first_step, obb_stream_t s);
+int obb_adamw_step(obb_ctx *ctx, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, obb_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

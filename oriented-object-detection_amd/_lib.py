@@ -59,6 +59,8 @@ SIGNATURES = {
     "obb_tile_labels": [_V, _V, C.c_int64, _V, C.c_int32, C.c_double, _V, _V, _V],
     "obb_dfl_loss": [_V, _V, _V, _V, C.c_int64, C.c_int32, C.c_float, _V, _V, _V],
     "obb_bce_loss": [_V, _V, _V, C.c_int64, C.c_float, _V, _V, _V],
+    "obb_sgd_step": [_V, _V, _V, _V, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _V],
+    "obb_adamw_step": [_V, _V, _V, _V, _V, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _V],
 }
 _RESTYPE = {"obb_last_error": C.c_char_p}
 

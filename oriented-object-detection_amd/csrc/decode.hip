@@ -841,7 +841,11 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
     const int slots = std::min<int>(kHeavySlots, B);
     int NPmax = 1024;
     while (NPmax < A) NPmax <<= 1;
-    if ((size_t)NPmax * 8 <= 128 * 1024) {
+    // Two forms for the flagged tiles, both bit-identical to the full path (tests): at predict-mode thresholds few tiles are flagged and
+    // they rarely reach max_det survivors, so the all-rows form (two launches) is the cheaper one (1024 tiles at conf 0.25: 375 us against
+    // 457 us with the round form's seven launches); at metrics-mode thresholds (conf 0.001: every tile flagged and saturated) the round
+    // form stops each tile at its max_det-th survivor (3.87 -> 1.1 ms).  The threshold is the caller's conf, the only thing the host knows.
+    if ((size_t)NPmax * 8 <= 128 * 1024 && conf_thres < 0.05f) {
         // round form: sort once, then rows in score order, kRoundRows at a time, until every tile has its max_det survivors
         static bool attr_set = false;
         if (!attr_set) {
@@ -850,17 +854,18 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
         }
         hipLaunchKernelGGL(k_heavy_bitonic, dim3((unsigned)std::min<int>(B, 256)), dim3(1024), (size_t)NPmax * 8, st, A, max_det, S);
         OBB_LAUNCH_CHECK(ctx);
-        // rounds of 512, 1024, then 2048 rows (multiples of k_heavy_out's 256-row chunks): most tiles finish inside the first two, and with
-        // nothing flagged (the usual predict-mode batch) the launches are empty -- few of them, on small grids
-        const int gx = std::min<int>(B, 256);
-        for (int r0 = 0, size = kRoundRows; r0 < A; size = std::min(2 * size, 2048)) {
-            const int r1 = std::min(A, r0 + size);
+        // equal rounds of kRoundRows (a multiple of k_heavy_out's 256-row chunks), one workgroup column per tile: a saturated tile has its
+        // max_det survivors after ~600-1000 rows, i.e. two rounds; growing rounds (512, 1024, 2048 on a 256-column grid) made it walk 1536
+        // rows against all their predecessors (0.76 -> 1.1 ms per 1024 tiles)
+        const int gx = std::min<int>(B, 65535);
+        for (int r0 = 0; r0 < A;) {
+            const int r1 = std::min(A, r0 + kRoundRows);
             hipLaunchKernelGGL(k_heavy_decode_rows, dim3((unsigned)gx, (unsigned)cdiv(r1 - r0, 256)), dim3(256), 0, st, head, A, nc, h, w, r0, r1, max_det, S);
             hipLaunchKernelGGL(k_heavy_nms_rows, dim3((unsigned)gx, 16), dim3(256), 0, st, A, iou_thres, r0, r1, kq, bdmax, S);
             OBB_LAUNCH_CHECK(ctx);
             r0 = r1;
         }
-    } else {  // more anchors than the LDS sort takes (inputs above ~900 x 900): the all-rows form
+    } else {  // the all-rows form (also: more anchors than the LDS sort takes, inputs above ~900 x 900)
         hipLaunchKernelGGL(k_heavy_sort, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, 30000, S);
         OBB_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(k_heavy_nms, dim3((unsigned)slots, 64), dim3(256), 0, st, A, iou_thres, 30000, kq, bdmax, S);

@@ -1,7 +1,8 @@
 """First slice of the training step: the ProbIoU rotated-box loss that `model.train(...)`
 (Train_OBB.py:796-841) reaches through Ultralytics' v8OBBLoss / RotatedBboxLoss, as an autograd function whose forward AND backward
 are one HIP kernel (csrc/loss.hip), plus the two other terms of that loss: DFL (box-side distributions) and BCE-with-logits (class
-scores).  Nothing else of training exists yet (assigner, conv backward, optimiser, DDP)."""
+scores).  The other slices of the step: ops.rotated_tal_assign (assigner), ops.conv_dgrad_bf16 / conv_wgrad_bf16 (conv backward), train.py
+(optimiser step, DDP gradient all-reduce)."""
 import torch
 
 from . import ops

@@ -220,6 +220,18 @@ def _bce_loss(logits: T, targets: T, target_scores_sum: float, loss: T, grad_log
     _call("obb_bce_loss", ctx(logits.device), _p(logits), _p(targets), logits.numel(), float(target_scores_sum), _p(loss), _p(grad_logits), _stream())
 
 
+@_op("sgd_step", ("param", "momentum_buf"))
+def _sgd_step(param: T, grad: T, momentum_buf: T, lr: float, momentum: float, weight_decay: float, nesterov: bool, first_step: bool) -> None:
+    _call("obb_sgd_step", ctx(param.device), _p(param), _p(grad), _p(momentum_buf), param.numel(), float(lr), float(momentum), float(weight_decay),
+          int(bool(nesterov)), int(bool(first_step)), _stream())
+
+
+@_op("adamw_step", ("param", "exp_avg", "exp_avg_sq"))
+def _adamw_step(param: T, grad: T, exp_avg: T, exp_avg_sq: T, step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float) -> None:
+    _call("obb_adamw_step", ctx(param.device), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step), float(lr), float(beta1), float(beta2),
+          float(eps), float(weight_decay), _stream())
+
+
 @_op("debug_activation", ("out",))
 def _debug_activation(name: str, B: int, h: int, w: int, out: T) -> None:
     n = C.c_int64(0)
@@ -671,6 +683,24 @@ def bce_loss(logits, targets, target_scores_sum=1.0):
     grad = torch.empty_like(x)
     _O.bce_loss(x, t, float(target_scores_sum), loss, grad)
     return loss, grad
+
+
+def sgd_step(param, grad, momentum_buf, lr, momentum=0.9, weight_decay=0.0, nesterov=True, first_step=False):
+    """In place, one launch: torch.optim.SGD's update (dampening 0) of a flat fp32 parameter group; `first_step` initialises the momentum
+    buffer with the (decayed) gradient as torch does."""
+    p, g, b = _chk(param, torch.float32, "param"), _chk(grad, torch.float32, "grad"), _chk(momentum_buf, torch.float32, "momentum_buf")
+    if not (p.numel() == g.numel() == b.numel()):
+        raise ValueError("sgd_step: size mismatch")
+    _O.sgd_step(p, g, b, float(lr), float(momentum), float(weight_decay), bool(nesterov), bool(first_step))
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """In place, one launch: torch.optim.AdamW's update of a flat fp32 parameter group; `step` counts from 1."""
+    p, g = _chk(param, torch.float32, "param"), _chk(grad, torch.float32, "grad")
+    m, v = _chk(exp_avg, torch.float32, "exp_avg"), _chk(exp_avg_sq, torch.float32, "exp_avg_sq")
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adamw_step: size mismatch")
+    _O.adamw_step(p, g, m, v, int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
 
 
 def probiou_loss(pred, target, weight=None, target_scores_sum=1.0):

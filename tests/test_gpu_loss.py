@@ -201,3 +201,48 @@ def test_conv_backward_bf16(B, H, W, cin, cout, ks):
     assert float(e_dw.max()) <= 2e-5 * sw  # fp32 sums of exact bf16 products: summation order only
     again = ops.conv_wgrad_bf16(x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda(), ks)
     assert torch.equal(again, dw)  # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 1024, 100003])
+@pytest.mark.parametrize("kind", ["sgd_nesterov", "sgd_plain", "sgd_nomom", "adamw"])
+def test_optimizer_steps_match_torch_optim(n, kind):
+    """csrc/optim.hip against torch.optim (the implementation Ultralytics' trainer calls) on the same parameters and gradients over 5 steps,
+    with the decay of the trainer's weight group (0.001) -- single-tensor reference order, so only fp32 rounding of reassociated constants
+    separates them."""
+    import oriented_object_detection_amd.train as TR
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.1 + k) for k in range(5)]
+    ref = torch.nn.Parameter(p0.clone().cuda())
+    if kind == "adamw":
+        topt = torch.optim.AdamW([ref], lr=0.000313, betas=(0.9, 0.999), weight_decay=0.001, foreach=False)
+        opt = TR.FlatOptimizer(n, "cuda", "AdamW", lr=0.000313, momentum=0.9, weight_decay=0.001)
+    else:
+        mu = 0.0 if kind == "sgd_nomom" else 0.9
+        nest = kind == "sgd_nesterov"
+        topt = torch.optim.SGD([ref], lr=0.01, momentum=mu, nesterov=nest, weight_decay=0.001, foreach=False)
+        opt = TR.FlatOptimizer(n, "cuda", "SGD", lr=0.01, momentum=mu, weight_decay=0.001, nesterov=nest)
+    opt.param.copy_(p0)
+    for k, gr in enumerate(grads):
+        ref.grad = gr.cuda()
+        topt.step()
+        opt.grad.copy_(gr)
+        opt.step()
+        d = (opt.param - ref.detach()).abs().max().item()
+        scale = ref.detach().abs().max().item()
+        assert d <= 2e-6 * max(1.0, scale), (kind, n, k, d)
+
+
+@pytest.mark.gpu
+def test_flat_optimizer_views_receive_gradients():
+    import oriented_object_detection_amd.train as TR
+    shapes = [(16, 8, 3, 3), (16,), (5, 7)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    opt = TR.FlatOptimizer(n, "cuda", "SGD", lr=0.5, momentum=0.0, weight_decay=0.0, nesterov=False)
+    pv, gv = TR.FlatOptimizer.views(opt.param, shapes), TR.FlatOptimizer.views(opt.grad, shapes)
+    for i, t in enumerate(gv):
+        t.fill_(float(i + 1))
+    opt.step()
+    for i, t in enumerate(pv):
+        assert torch.equal(t, torch.full_like(t, -0.5 * (i + 1)))

@@ -494,7 +494,7 @@ static int ilog2_(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 static int c32_kfull(int ks, int CK) { return ks == 3 ? (9 * (CK / 4)) / 4 : (CK / 4 + 3) / 4; }
 static int c32_krem(int ks, int CK) { return ks == 3 ? (9 * (CK / 4)) % 4 : 0; }
 static int c32_wfloats(int ks, int CK) { return c32_kfull(ks, CK) * 256 + c32_krem(ks, CK) * 64; }
-static int c32_mfm_max(int WC) { return WC == 4 ? 7 : (WC == 2 ? 4 : 2); }  // 224 / 256 / 256 pixels per tile
+static int c32_mfm_max(int WC) { return WC == 4 ? 7 : 4; }  // 224 / 256 / 512 pixels per tile
 static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
 static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
 
@@ -710,6 +710,8 @@ static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, int tai
         case 2 * 16 + 4: return launch32_f<KS, 4, 2>(L, P, tail_wc2, grid, lds, st);
         case 2 * 16 + 3: return launch32_f<KS, 3, 2>(L, P, tail_wc2, grid, lds, st);
         case 2 * 16 + 2: return launch32_f<KS, 2, 2>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 4: return launch32_f<KS, 4, 1>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 3: return launch32_f<KS, 3, 1>(L, P, tail_wc2, grid, lds, st);
         case 1 * 16 + 2: return launch32_f<KS, 2, 1>(L, P, tail_wc2, grid, lds, st);
         case 1 * 16 + 1: return launch32_f<KS, 1, 1>(L, P, tail_wc2, grid, lds, st);
     }

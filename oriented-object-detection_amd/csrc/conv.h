@@ -54,6 +54,10 @@ struct ConvLaunch {
     // tiling (chosen by plan_conv)
     int TH = 1, TW = 64, MF = 1, NF = 4, CK = 32;
     int tiles_y = 1, tiles_x = 1;
+    // NI > 1: one tile = NI whole images of a small map (TH x TW = Hout x Wout, NI * TH * TW <= 64 * MF): the 4 x 4 level of the 128-px scale
+    // would otherwise run as 8 x 8 tiles, three quarters of them padding.  3x3 layers with 64-cout groups and a 16-bit output only
+    // (conv_ni_supported).
+    int NI = 1;
 };
 
 struct ConvTiling { int TH, TW, MF, NF, CK; };
@@ -70,6 +74,8 @@ std::vector<bf16_t> pack_conv_weights(const float *w_oihw, int cout, int cin, in
 int conv_ksteps(int ks, int CK);
 size_t conv_lds_bytes(const ConvLaunch &L);
 bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16 = false, int TH = 0);
+// NI (images per tile) for a launch planned on the generic small-map tile, or 1: the shapes the multi-image form has a kernel path for
+int conv_ni_supported(const ConvLaunch &L);
 hipError_t launch_conv(const ConvLaunch &L, hipStream_t st);
 
 }  // namespace obb

@@ -57,6 +57,7 @@ struct ConvParams {
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/8)*/, tiles_x, tiles_y, nstage, kst, out_hw, act_bytes;
     int tpw, ntiles;  // consecutive pixel tiles per workgroup; total pixel tiles (batch included)
+    int NI, B;        // NI > 1: a tile = NI whole images of a small map (TH x TW = the map: the 4 x 4 level of the 128-px scale), B images in all
     int gx, ncb;      // workgroups along the tile axis; cout blocks
     unsigned in_span_bytes, w_bytes;  // buffer-descriptor ranges: bytes of one image's input slice span; bytes of the packed weights
     // 1x1 over a virtual concat [nearest-x2 upsample of a low-res tensor | full-res tensor] (1-D launches only): channels [0, up_c) come
@@ -79,7 +80,9 @@ struct ConvParams {
 // (13 x 13 + halo, all channels) is ONE set of loads, prefetched into registers a whole tile ahead.  The multi-stage form pays a
 // global-memory latency per 16-channel stage (4 per tile at cin = 64) with 60 MFMAs of cover each; here a tile is 216 MFMAs back to
 // back behind a single, fully covered latency.  One group per CU (104 KiB of LDS), one wave per SIMD: no register limit to respect.
-template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false, bool WRES = false>
+// NIT: multi-image tiles (ConvParams::NI > 1) -- a separate instantiation of the one shape that has them (3x3, one fragment per wave, 64-cout
+// groups, register-direct stores), so that the index arithmetic of the form costs the other variants, all at their register caps, nothing.
+template <int KS, int MF, int NF, bool IN_U8, bool OUT_F32, bool F16, int TAIL = 0, bool VCAT = false, bool T16 = false, bool WRES = false, bool NIT = false>
 // Register budget: the 64-cout 3x3 variants need ~210 VGPRs (two waves per SIMD); everything else fits 168 without spills, which is the
 // difference between two and three resident waves per SIMD (allocation granule 8: 170 registers already drop to two).
 __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : MF == 3)) ? 2 : 3)) void k_conv_igemm(const ConvParams P) {
@@ -95,7 +98,8 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                                                  // 8-channel input layer packs pixels densely: twice the groups per CU)
     const int cpk = P.CK >> 3;
     const int nq = (KS == 3 ? 9 : 1) * cpk;
-    const int in_px = THin * TWin;
+    const int in_px1 = THin * TWin;      // staged pixels of one image
+    const int in_px = NIT ? in_px1 * P.NI : in_px1;
     const int nchunk = in_px << P.sh;
     // XCD-aware launch order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The groups that compute
     // different cout blocks of the SAME pixel tiles read the same input: they are made consecutive on one XCD, so the second and
@@ -118,15 +122,18 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
     }
 
     // ---- tile-independent per-lane state
-    int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (ty << 16 | tx) or -1
+    int pixbase[MF], ptyx[MF];  // LDS byte offset of the lane's pixel (one per M fragment); (image-in-tile << 24 | ty << 16 | tx) or -1
+    const int tpi = P.TH * P.TW;   // output pixels of one image's part of the tile
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         int p = (wave * MF + mf) * 16 + pl;
-        int ty = (int)(((float)p + 0.5f) * P.inv_tw);
-        int tx = p - ty * P.TW;
-        bool ok = p < P.TH * P.TW;
-        pixbase[mf] = ok ? ((ty * S) * TWin + tx * S) * PST : 0;
-        ptyx[mf] = ok ? ((ty << 16) | tx) : -1;
+        const int il = NIT ? (int)(((float)p + 0.5f) / (float)tpi) : 0;
+        const int q = p - il * tpi;
+        int ty = (int)(((float)q + 0.5f) * P.inv_tw);
+        int tx = q - ty * P.TW;
+        bool ok = p < (NIT ? tpi * P.NI : tpi);
+        pixbase[mf] = ok ? (il * in_px1 + (ty * S) * TWin + tx * S) * PST : 0;
+        ptyx[mf] = ok ? ((il << 24) | (ty << 16) | tx) : -1;
     }
     // staging plan: this thread moves the 16-B chunks idx = tid + k*256 of the [in_px][CK] tile
     constexpr int MAXLD = WRES ? 8 : ((KS == 1) ? 4 : 6);
@@ -137,9 +144,11 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
         for (int k = 0; k < MAXLD; ++k) {
             int idx = tid + k * 256;
             int pix = idx >> P.sh;
+            const int il = NIT ? (int)(((float)pix + 0.5f) / (float)in_px1) : 0;
+            pix -= il * in_px1;
             int iy = (int)(((float)pix + 0.5f) * P.inv_twin);
             int ix = pix - iy * TWin;
-            ipos[k] = idx < nchunk ? ((iy << 16) | ix) : -1;
+            ipos[k] = idx < nchunk ? ((il << 24) | (iy << 16) | ix) : -1;
         }
     }
     const int cbase = cb * 16 * NF + g * 4 * NF;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
         int tx_i = t % P.tiles_x;
         int r = t / P.tiles_x;
         int ty_i = r % P.tiles_y;
-        b = r / P.tiles_y;
+        b = NIT ? t * P.NI : r / P.tiles_y;  // (first) image of the tile
         oy0 = ty_i * P.TH; ox0 = tx_i * P.TW;
     };
     // Activations are fetched with buffer loads (one 32-bit byte offset per chunk, descriptor in SGPRs): the descriptor's range
@@ -174,8 +183,9 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
         in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)P.in_span_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < MAXLD; ++k) {
-            int gy = iy0 + (ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
-            bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+            const int il = NIT ? ipos[k] >> 24 : 0;
+            int gy = iy0 + (NIT ? (ipos[k] >> 16) & 0xff : ipos[k] >> 16), gx = ix0 + (ipos[k] & 0xffff);
+            bool ok = ipos[k] >= 0 && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win && (!NIT || b + il < P.B);
             if constexpr (VCAT) {  // gx = pixel index over the whole batch at full resolution
                 const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
                 const int yy = r / P.up_W, xx = r - yy * P.up_W;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                 goff[k] = ok ? (unsigned)(sp * P.in_cs * 2) : NOPIX;
                 goff2[k] = ok ? (unsigned)((int64_t)gx * P.in2_cs * 2) : NOPIX;
             } else {
-                goff[k] = ok ? (unsigned)(((int64_t)gy * P.Win + gx) * P.in_cs * 2) : NOPIX;  // pixel part; the chunk part is added per stage
+                goff[k] = ok ? (unsigned)(((NIT ? (int64_t)il * P.in_bs : 0) + ((int64_t)gy * P.Win + gx) * P.in_cs) * 2) : NOPIX;  // (image-in-tile +) pixel part; the chunk part is added per stage
             }
         }
     };
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
     // prologue's loads are settled before the loop so that the loop-entry state is "nothing outstanding".  Without this every tile
     // drained its predecessor's stores before touching LDS (ISA: s_waitcnt vmcnt(0) at the top of every stage).
     constexpr bool EXACT = DIRECT && !VCAT && !WRES;
+    static_assert(!NIT || (EXACT && KS == 3 && MF == 1), "multi-image tiles: the register-direct store path only");
     if constexpr (EXACT) __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));  // vmcnt(0)
     STAMP_INIT
 
@@ -426,10 +437,10 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
         if constexpr (!OUT_F32 && !DIRECT) __syncthreads();  // every wave is done reading the input tile: its LDS becomes the output staging area
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-            int ty = ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff;
-            bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout) && !(P.dbg & 8);
+            int ty = NIT ? (ptyx[mf] >> 16) & 0xff : ptyx[mf] >> 16, tx = ptyx[mf] & 0xffff, il = NIT ? ptyx[mf] >> 24 : 0;
+            bool ok = ptyx[mf] >= 0 && (oy0 + ty < P.Hout) && (ox0 + tx < P.Wout) && (!NIT || b + il < P.B) && !(P.dbg & 8);
             if constexpr (!EXACT) { if (!ok) continue; }
-            else if (!ok) { ty = 0; tx = 0; }  // (addresses stay in range; the stores below go to the sink)
+            else if (!ok) { ty = 0; tx = 0; il = 0; }  // (addresses stay in range; the stores below go to the sink)
             const int64_t opix = (int64_t)(oy0 + ty) * P.Wout + ox0 + tx;
             float v[NF * 4];
 #pragma unroll
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                 for (int c = 0; c < NF * 4; ++c) v[c] = silu_f(v[c]);
             }
             if (P.res) {
-                const bf16_t *rp = P.res + (int64_t)b * P.res_bs + opix * P.res_cs + P.res_co + (int64_t)((cbase >> 3) >> P.res_bsh) * P.res_ps +
+                const bf16_t *rp = P.res + (int64_t)(b + il) * P.res_bs + opix * P.res_cs + P.res_co + (int64_t)((cbase >> 3) >> P.res_bsh) * P.res_ps +
                                    (((cbase >> 3) & P.res_bmask) << 3) + (cbase & 7);
                 if (full) {
 #pragma unroll
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(256, WRES ? 1 : ((NF == 4 && (KS == 3 ? MF >= 2 : M
                         if (cbase + c < P.cout) op[c] = v[c];
                 }
             } else if constexpr (DIRECT) {
-                bf16_t *obase = (bf16_t *)P.out + (int64_t)b * P.out_bs + P.out_co + opix * P.out_cs;
+                bf16_t *obase = (bf16_t *)P.out + (int64_t)(b + il) * P.out_bs + P.out_co + opix * P.out_cs;
 #pragma unroll
                 for (int h = 0; h < NF / 2; ++h) {
                     uint4 o;
@@ -986,7 +997,7 @@ static bool conv_pair(const ConvLaunch &L) {
 // their weights resident across tiles, so there the staging area must fit in front of them.
 static size_t conv_act_bytes(const ConvLaunch &L) {
     int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    size_t in_tile = (size_t)THin * TWin * (L.in_u8 ? 16 : L.CK * 2 + 16);
+    size_t in_tile = (size_t)std::max(1, L.NI) * THin * TWin * (L.in_u8 ? 16 : L.CK * 2 + 16);
     size_t out_tile = L.out_f32 ? 0 : (size_t)64 * L.MF * (32 * L.NF + 16);
     size_t a = conv_multi_stage(L) ? in_tile : std::max(in_tile, out_tile);
     return (a + 15) / 16 * 16;
@@ -1002,6 +1013,13 @@ static int tail_nf(int cout2) { return cout2 <= 16 ? 1 : (cout2 <= 32 ? 2 : 4); 
 size_t conv_lds_bytes(const ConvLaunch &L) {
     size_t t = L.tail_cout > 0 ? (size_t)conv_ksteps(1, 16 * L.NF) * tail_nf(L.tail_cout) * 1024 : 0;  // tail weights behind everything else
     return conv_main_lds(L) + t;
+}
+
+int conv_ni_supported(const ConvLaunch &L) {
+    // the register-direct store path of k_conv_igemm (64-cout groups, no tail, 16-bit plain-NHWC output) on the one-fragment-per-wave tile
+    if (L.ks != 3 || L.NF != 4 || L.MF != 1 || L.in_u8 || L.out_f32 || L.tail_cout > 0 || L.up_c > 0 || L.CK > 16) return 1;  // (channel-blocked slices included: an image is one stride inside every block plane)
+    if (L.Hout != L.Wout || (L.Hout != 4 && L.Hout != 2)) return 1;
+    return 64 / (L.Hout * L.Wout);
 }
 
 bool conv_tail_supported(int ks, int MF, int NF, int cout1, int cout2, bool act16, int TH) {
@@ -1071,7 +1089,10 @@ static hipError_t launch_t2(const ConvLaunch &L, const ConvParams &P, dim3 grid,
         if constexpr (KS == 3) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, true, false, F16>), grid, dim3(256), lds, st, P);
         else return hipErrorInvalidValue;
     } else if (L.out_f32) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, true, F16>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16>), grid, dim3(256), lds, st, P);
+    else if (P.NI > 1) {
+        if constexpr (KS == 3 && MF == 1 && NF == 4) hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16, 0, false, false, false, true>), grid, dim3(256), lds, st, P);
+        else return hipErrorInvalidValue;
+    } else hipLaunchKernelGGL((k_conv_igemm<KS, MF, NF, false, false, F16>), grid, dim3(256), lds, st, P);
     return hipGetLastError();
 }
 
@@ -1160,6 +1181,9 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act; P.flip_bgr = L.flip_bgr;
     P.TH = L.TH; P.TW = L.TW; P.CK = L.CK; P.sh = ilog2(L.CK / 8);
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw; P.act_bytes = (int)conv_act_bytes(L);
+    const int NI = std::max(1, L.NI);
+    P.NI = NI; P.B = L.B;
+    if (NI > 1 && (NI != conv_ni_supported(L) || L.TH != L.Hout || L.TW != L.Wout || L.tiles_x != 1 || L.tiles_y != 1 || L.out_hw)) return hipErrorInvalidValue;
 #if defined(OBB_STAMPS) || defined(OBB_DIAG)  // timing-only ablations exist in the diagnostic build alone (tools/stamp_conv.sh): the product library ignores the variable
     static const int dbg = getenv("OBB_CONV_DBG") ? atoi(getenv("OBB_CONV_DBG")) : 0;
     P.dbg = dbg;
@@ -1195,6 +1219,7 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
         int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 2;  // from the slice's first element to the end of the image
         if (L.in.cpb > 0) span = (in_block_span + (int64_t)L.Hin * L.Win * L.in.cs) * 2;  // ... to the end of the slice's last block
         if (L.up_c > 0) span = ((int64_t)(L.Win / 4) * L.in.cs - L.in.co) * 2;  // the low-res source of a virtual concat
+        span += (int64_t)(NI - 1) * L.in.bs * 2;  // a multi-image tile reads up to the end of its last image
         int64_t wb = (int64_t)((L.cout + 16 * L.NF - 1) / (16 * L.NF)) * P.nstage * P.kst * L.NF * 1024;
         if (span <= 0 || span >= (1ll << 32) - 65536 || wb >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = (unsigned)span;
@@ -1204,14 +1229,14 @@ static hipError_t launch_conv_impl(const ConvLaunch &L, hipStream_t st, unsigned
     int TWin = (L.TW - 1) * L.stride + L.ks;
     P.inv_twin = 1.0f / (float)TWin;
     P.inv_tw = 1.0f / (float)L.TW;
-    if ((1 << P.sh) != L.CK / 8 || L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
+    if ((1 << P.sh) != L.CK / 8 || NI * L.TH * L.TW > 64 * L.MF || L.MF < 1 || L.MF > 3) return hipErrorInvalidValue;
     {
         int THin = (L.TH - 1) * L.stride + L.ks;
-        if (!L.in_u8 && (int64_t)THin * TWin * (L.CK / 8) > (conv_wres(L) ? 8 : (L.ks == 1 ? 4 : 6)) * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
+        if (!L.in_u8 && (int64_t)NI * THin * TWin * (L.CK / 8) > (conv_wres(L) ? 8 : (L.ks == 1 ? 4 : 6)) * 256) return hipErrorInvalidValue;  // staging plan: chunks per thread
         if (L.ks == 1 && L.CK > 64) return hipErrorInvalidValue;
     }
     int ncb = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
-    int64_t ntiles = (int64_t)L.B * L.tiles_y * L.tiles_x;
+    int64_t ntiles = NI > 1 ? ((int64_t)L.B + NI - 1) / NI : (int64_t)L.B * L.tiles_y * L.tiles_x;
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
     if (conv_pair(L)) {  // one 512-thread workgroup per CU, its two halves walking alternate tiles

@@ -1053,6 +1053,9 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     int64_t npx = (int64_t)B * op.Ho * op.Wo;
                     L.B = 1; L.Hin = L.Hout = 1; L.Win = L.Wout = (int)npx;
                     L.tiles_y = 1; L.tiles_x = (int)((npx + L.TW - 1) / L.TW);
+                } else if (M.o.nitile) {  // the 4 x 4 / 2 x 2 maps of small tiles: several whole images per 64-pixel tile
+                    const int ni = conv_ni_supported(L);
+                    if (ni > 1) { L.NI = ni; L.TH = L.Hout; L.TW = L.Wout; L.tiles_x = L.tiles_y = 1; }
                 }
                 e = launch_conv(L, st);
                 break;
@@ -1228,7 +1231,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
@@ -1352,8 +1355,9 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
                 grid_y = (L.cout + 16 * L.NF - 1) / (16 * L.NF);
                 lds = (int)conv_lds_bytes(L);
                 if (L.tail_cout > 0) macs += (double)op.Ho * op.Wo * L.tail_cout * L.cout;
-                snprintf(line, sizeof line, "%s %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d MF%d NF%d CK%d gx%d gy%d lds%d macs%.0f\n", ty,
-                         op.name.c_str(), L.ks, L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.MF, L.NF, L.CK, grid_x, grid_y, lds, macs);
+                const int ni = (!op.one_d && ctx->model->o.nitile) ? conv_ni_supported(L) : 1;  // (decided per launch: images per tile on the small maps)
+                snprintf(line, sizeof line, "%s %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d MF%d NF%d CK%d NI%d gx%d gy%d lds%d macs%.0f\n", ty,
+                         op.name.c_str(), L.ks, L.stride, L.cin, L.cout, op.Ho, op.Wo, ni > 1 ? op.Ho : L.TH, ni > 1 ? op.Wo : L.TW, L.MF, L.NF, L.CK, ni, grid_x, grid_y, lds, macs);
                 break;
             }
             case OP_DW: ty = "dwconv"; macs = (double)op.H * op.W * op.in.C * 9;

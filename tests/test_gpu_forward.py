@@ -170,6 +170,23 @@ def test_pair_kernel_matches_staged_kernel(ops, net_n):
     assert float(dh.max()) < (0.3 if net_n.prec == "f16" else 2.0) and float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), (float(dh.max()), float(dh.mean()))
 
 
+@pytest.mark.parametrize("h,w,B", [(128, 128, 5), (128, 128, 1030), (64, 64, 37), (128, 64, 6)])
+def test_multi_image_tiles_are_bit_identical(ops, net_n, h, w, B):
+    """`nitile`: the 3x3 convs on 4 x 4 / 2 x 2 maps take several whole images per 64-pixel tile (k_conv_igemm NIT) instead of one image
+    padded to an 8 x 8 tile -- same operands, same k order, so the head must agree BIT FOR BIT; batch sizes that leave the last tile partly
+    empty, a batch above one round and a non-square tile (no 4 x 4 / 2 x 2 level of its own shape: plan unchanged) included."""
+    x = torch.as_tensor(_tiles(5 + h + B, B, h, w)).cuda()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec, nitile=False)
+    assert not any(" NI4 " in l or " NI16 " in l for l in ops.debug_plan(h, w))
+    one = ops.forward(x).clone()
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)
+    plan = ops.debug_plan(h, w)
+    if h == w:
+        assert any(" NI4 " in l for l in plan), plan
+    ni = ops.forward(x)
+    assert torch.equal(one[..., :77], ni[..., :77]), float((one - ni)[..., :77].abs().max())
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 2), (192, 416, 2), (64, 96, 3)])
 def test_tail_fusion_matches_separate_launches(ops, net_n, h, w, B):
     """The fused trailing 1x1 reads the producer's 16-bit output from LDS instead of HBM: same values, same k order -> identical head."""

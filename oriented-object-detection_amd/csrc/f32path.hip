@@ -646,7 +646,10 @@ static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStre
     P.tstep = 0;
     // (measured per layer, 512 tiles: layers of 1-3 stages per tile gain 3-18 % -- model.2.cv2 867 -> 707 us -- longer tiles hide their
     // first fetch and their stores behind the co-resident workgroup anyway and only lose to the coarser tile split)
-    if (TAIL == 0 && !DW && !IN_U8 && P0.tstep != 0 && P0.nstage <= 3) {  // (launch_conv32 passes Conv32Launch::xtile in tstep)
+#ifndef OBB_XT_MAX_STAGES
+#define OBB_XT_MAX_STAGES 3
+#endif
+    if (TAIL == 0 && !DW && !IN_U8 && P0.tstep != 0 && P0.nstage <= OBB_XT_MAX_STAGES) {  // (launch_conv32 passes Conv32Launch::xtile in tstep)
         // cross-tile pipeline: a grid of resident workgroups, each walking ~equally many tiles (see XT in the kernel)
         static std::map<size_t, int> occ;  // resident workgroups per CU of this instantiation, by dynamic LDS size
         static int ncu = 0;

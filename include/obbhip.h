@@ -61,6 +61,7 @@ const char *obb_last_error(const obb_ctx *ctx);
  *     "sppf_fuse" the three SPPF pools in one launch                                   "attn_mfma" C2PSA attention on the matrix cores
  *     "front"     model.0 + model.1 + model.2.cv1 as one launch (tile sides % 52 == 0)  "pair"      64 -> 64-cout 3x3 convs on k_conv3_pair
  *     "nitile"    (16-bit modes) several whole images per tile on the 4 x 4 / 2 x 2 maps of small tiles (3x3 convs with 64-cout groups)
+ *     "nc2"       (fp32) two cout fragments per wave (32 couts x <= 64 pixels) in the conv kernel where the plan allows: a third fewer LDS reads
  *     "xtile"     (fp32) conv workgroups stay resident and walk several tiles, the next tile's first stage fetched under this tile's last k loop
  *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 0..4
  *   concurrent sub-batch chains (default 0 = 2), "microbatch" 416 x 416 tiles per round (default and maximum 1024; smaller tiles

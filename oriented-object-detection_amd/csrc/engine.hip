@@ -333,12 +333,12 @@ struct Builder {
         if (M.f32) {  // fp32-arithmetic mode: exact-f32 MFMA kernels (f32path.hip)
             op.type = OP_CONV32;
             Conv32Launch &L = op.c32;
-            const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8, op.vin);
+            const Conv32Tiling t = plan_conv32(r->k, r->s, cin, r->c2, op.Ho, op.Wo, in_u8, op.vin, M.o.nc2 && !tail_name);
             L.ks = r->k; L.stride = r->s; L.cin = cin; L.cout = r->c2; L.act = r->act; L.in_u8 = in_u8; L.flip_bgr = (in_u8 && M.ch == 3);
-            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM; L.NI = t.NI;
+            L.TH = t.TH; L.TW = t.TW; L.CK = t.CK; L.WC = t.WC; L.MFM = t.MFM; L.NI = t.NI; L.NC = std::max(1, t.NC);
             L.Hin = Hin; L.Win = Win; L.Hout = op.Ho; L.Wout = op.Wo;
             L.tiles_y = (op.Ho + t.TH - 1) / t.TH; L.tiles_x = (op.Wo + t.TW - 1) / t.TW;
-            if (op.vin && (P.bufs[in.buf].va_C % t.CK || t.WC != 4)) { err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the virtual concat in fp32 mode", name.c_str()); return; }
+            if (op.vin && (P.bufs[in.buf].va_C % t.CK || (t.WC != 4 && t.NC != 2))) { err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the virtual concat in fp32 mode", name.c_str()); return; }
             L.wpk = upload(pack_conv32_weights(r->w, r->c2, cin, r->k, t, perm, in_u8));
             std::vector<float> bias32(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
             for (int c = 0; c < r->c2; ++c) bias32[c] = r->b[perm ? perm[c] : c];
@@ -1231,7 +1231,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
@@ -1343,8 +1343,8 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
         switch (op.type) {
             case OP_CONV32: {
                 const Conv32Launch &L = op.c32;
-                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d NI%d CK%d WC%d MFM%d dw%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
-                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.NI, L.CK, L.WC, L.MFM, L.dw, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
+                snprintf(line, sizeof line, "conv32 %s k%d s%d cin%d cout%d out%dx%d TH%d TW%d NI%d CK%d WC%d NC%d MFM%d dw%d tail%d vcat%d lds%d macs%.0f\n", op.name.c_str(), L.ks,
+                         L.stride, L.cin, L.cout, op.Ho, op.Wo, L.TH, L.TW, L.NI, L.CK, L.WC, L.NC, L.MFM, L.dw, L.tail_cout, op.vin ? 1 : 0, (int)conv32_lds_bytes(L), op.macs);
                 break;
             }
             case OP_CONV: {

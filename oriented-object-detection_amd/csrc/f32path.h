@@ -40,11 +40,13 @@ struct Conv32Launch {
     int dw = 0, dw_act = 1;  // dw: a depthwise 3x3 (+ bias, SiLU if dw_act) runs in front of this 1x1 inside the launch (wpk from pack_dwpw32_weights)
     int NI = 1;  // > 1: one tile = NI whole images of a small map (TH x TW = the map; the 8 x 8 / 4 x 4 levels of the 128-px scale)
     int tiles_y = 1, tiles_x = 1;
+    int NC = 1;  // cout fragments per wave: 2 = WC waves x 32 couts, MFM <= 4 pixel fragments (plain / VCAT forms; wpk packed for it)
     int xtile = 1;  // resident workgroups that walk several tiles, the next tile's first stage fetched under this tile's last k loop (plain / VCAT forms)
 };
 
-struct Conv32Tiling { int TH, TW, CK, WC, MFM, NI; };
-Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat = false);  // vcat: the input is a virtual [upsample | skip] concat
+struct Conv32Tiling { int TH, TW, CK, WC, MFM, NI, NC; };  // (NC 0 / 1: one cout fragment per wave)
+// vcat: the input is a virtual [upsample | skip] concat; nc2: the layer may take the two-fragments-per-wave form (no tail, no depthwise prologue)
+Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat = false, bool nc2 = false);
 // true if the 1x1 conv (cout1 -> cout2) can run as the fused tail of a layer tiled as `t`
 bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2);
 // DWConv 3x3 -> Conv 1x1 as one launch (k_conv_f32 DW): tiling (TH = 0: no kernel for the shapes) and the per-stage weight blocks

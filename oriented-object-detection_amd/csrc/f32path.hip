@@ -68,8 +68,15 @@ __device__ __forceinline__ float silu32(float x) { return x * __builtin_amdgcn_r
 //     one-pixel halo, every thread computes depthwise outputs for its (pixel, 4-channel chunk) items straight from that LDS tile (taps in
 //     (ky, kx) order like k_dwconv3_f32, weights from the stage's weight block) and writes them where the 1x1's B operand is read -- the
 //     depthwise tensor never exists in memory (the class branch of the head: DWConv -> Conv 1x1 [-> Conv 1x1 to the head rows]).
-template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL, bool DW = false>
+//   * NC = 2 (plain and VCAT forms): a wave owns TWO cout fragments (32 couts) x MFM <= 4 pixel fragments instead of one x 7: WC = 2 waves along
+//     cout, 4 along the pixels, tiles of <= 256 pixels x 64 couts.  Six operand reads (2 weight + 4 activation pieces) feed 32 MFMAs where
+//     the 1 x 7 shape needs eight for 28 -- the k loop turned out to be sensitive to its LDS reads (doubling the activation reads in a
+//     timing-only build cost 20-27 % on every MFMA-bound layer) -- and with the cout order below a lane's eight couts are 32 contiguous
+//     bytes, the four lanes of a pixel a whole 128-byte line.  Fragment nc, accumulator row g * 4 + j <-> cout 32 * block + g * 8 + nc * 4 + j
+//     (pack_conv32_weights permutes the rows accordingly).
+template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P) {  // <= 128 VGPRs: two workgroups per CU
+    static_assert(NC == 1 || (NC == 2 && TAIL == 0 && !DW && !IN_U8), "two cout fragments per wave: plain / VCAT forms only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SKS = DW ? 3 : KS;  // kernel size the STAGING sees (halo); the MFMA loop sees KS
     constexpr int NT = NW * 64, WP = NW / WC, PAD = SKS / 2;
@@ -110,11 +117,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         if constexpr (DW) pixbase[mf] = (p < npix ? p : 0) * PST;  // (relative to the depthwise-output tile, added below)
         else pixbase[mf] = p < npix ? (il * in_px1 + (ty * S) * TWin + tx * S) * PST : 0;  // fragments past the tile compute on pixel 0 and are dropped
     }
-    const int F = cb * WC + wc;  // cout fragment of this wave
+    const int F = (cb * WC + wc) * NC;  // (first) cout fragment of this wave
     // weights of (cout block cb, stage): WC * kst pieces of 1 KiB, contiguous (pack_conv32_weights); LDS image behind the activation tile
     const int dwb_off = ((in_px * PST + 1023) >> 10) << 10;  // DW: the depthwise-output tile [npix][CK] behind the input tile
     const int act_bytes = DW ? dwb_off + (((npix * PST + 1023) >> 10) << 10) : dwb_off;
-    const int nwchunk = WC * (P.wcb >> 4) + (DW ? 10 * cpk : 0);  // 16-B chunks of one stage's weights (+ DW: 9 taps + bias of the stage's channels)
+    const int nwchunk = WC * NC * (P.wcb >> 4) + (DW ? 10 * cpk : 0);  // 16-B chunks of one stage's weights (+ DW: 9 taps + bias of the stage's channels)
     if constexpr (DW) {
 #pragma unroll
         for (int mf = 0; mf < MFM; ++mf) pixbase[mf] += dwb_off;
@@ -122,15 +129,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(P.wpk + (size_t)cb * P.nstage * nwchunk * 4), 0, P.nstage * nwchunk * 16, 0x00020000);
     char *const wlds = smem + act_bytes;
 
-    f32x4 acc[MFM];
+    f32x4 acc[NC][MFM];
 #pragma unroll
-    for (int mf = 0; mf < MFM; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int mf = 0; mf < MFM; ++mf) acc[nc][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging plan: this thread moves the 16-B chunks idx = tid + k * NT of the [in_px][CK] tile.  Activations come through buffer
     // loads (descriptor in SGPRs, one 32-bit byte offset per chunk): an offset past the descriptor's range reads zeros, which is how
     // the zero padding is written
     constexpr int MAXLD = IN_U8 ? 3 : (KS == 1 ? (DW ? 3 : (VCAT ? 4 : 7)) : 5);  // plan_conv32 keeps a stage within that many x NT chunks of 16 B
-    constexpr int MAXW = (WC * (KS == 3 ? 9 : 4) * 64 + (DW ? 10 * 8 : 0) + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4; DW: + 10 x CK floats, CK <= 32)
+    constexpr int MAXW = (WC * NC * (KS == 3 ? 9 : 4) * 64 + (DW ? 10 * 8 : 0) + NT - 1) / NT;  // weight chunks per thread and stage (kst <= 9 / 4; DW: + 10 x CK floats, CK <= 32)
     constexpr unsigned NOPIX = 0xffffffffu;
     const int nchunk = in_px * cpk;
     unsigned goff[IN_U8 ? 1 : MAXLD], goff2[VCAT ? MAXLD : 1];
@@ -262,13 +271,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     }
     commit();
     __syncthreads();
-    const char *const wfrag = wlds + wc * P.wcb + lane * 16;
-    const char *const wrem = wlds + wc * P.wcb + P.kst * 1024 + lane * 4;  // the remainder chunks' weights: [chunk][lane] floats
-    const int cbase = F * 16 + g * 4;  // epilogue: lane owns couts [cbase, cbase + 4) of its pixels
+    const char *const wfrag = wlds + wc * NC * P.wcb + lane * 16;  // (NC = 2: the second fragment's block follows at + wcb)
+    const char *const wrem = wlds + wc * NC * P.wcb + P.kst * 1024 + lane * 4;  // the remainder chunks' weights: [chunk][lane] floats
+    const int cbase = F * 16 + g * 4 * NC;  // epilogue: lane owns couts [cbase, cbase + 4 NC) of its pixels (NC = 2: fragment nc holds [cbase + 4 nc, + 4))
     // (the bias is loaded ONCE, outside the tile loop: a load inside it whose uses sit behind the per-pixel guards stays "pending" for the
     // compiler on the skipping paths, and the first LDS read of the next k loop that reuses its register then waits vmcnt(0) -- i.e. for
     // the stage prefetch issued just before)
-    const float4 bv = TAIL > 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(P.bias + cbase);  // bias is padded: always readable
+    float4 bvn[NC];  // bias is padded: always readable
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) bvn[nc] = TAIL > 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(P.bias + cbase + 4 * nc);
     for (;;) {
     bool more = false;  // (XT) the next tile's first stage is in flight / in LDS
     for (int stage = 0; stage < P.nstage; ++stage) {
@@ -304,7 +315,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         }
         if (!last || more) fetch(fstage);
         for (int ks = 0; ks < P.kst; ++ks) {
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(wfrag + ks * 1024);
+            f32x4 w[NC];
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) w[nc] = *reinterpret_cast<const f32x4 *>(wfrag + nc * P.wcb + ks * 1024);
             int q = ks * 4 + g;
             if constexpr (KS == 1) q = q < nq ? q : nq - 1;  // (1x1: the last piece may be padded -- any valid address, its weights are zero)
             int off;
@@ -326,10 +339,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int i = 0; i < H; ++i) {
-                        if (m0 + i < MFM - 1) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[m0 + i], 0, 0, 0);
-                        else if (m0 + i == MFM - 1) { if (cur.lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc[MFM - 1], 0, 0, 0); }
-                    }
+                    for (int i = 0; i < H; ++i)
+#pragma unroll
+                        for (int nc = 0; nc < NC; ++nc) {
+                            if (m0 + i < MFM - 1) acc[nc][m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nc][s], a[i][s], acc[nc][m0 + i], 0, 0, 0);
+                            else if (m0 + i == MFM - 1) { if (cur.lastv) acc[nc][MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nc][s], a[i][s], acc[nc][MFM - 1], 0, 0, 0); }
+                        }
             }
         }
         // the stage's last nq % 4 chunks, ONE MFMA each: the four k slots of the instruction are the chunk's four channels (lane group g
@@ -337,7 +352,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         // padding the stage to 5 pieces cost 20
         if constexpr (KS == 3)
         for (int r = 0; r < P.krem; ++r) {
-            const float w1 = *reinterpret_cast<const float *>(wrem + r * 256);
+            float w1[NC];
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) w1[nc] = *reinterpret_cast<const float *>(wrem + nc * P.wcb + r * 256);
             const int q = P.kst * 4 + r;
             const int tap = q >> P.sh, c0 = q & (cpk - 1);
             const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
@@ -346,10 +363,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
             for (int mf = 0; mf < MFM; ++mf) a1[mf] = *reinterpret_cast<const float *>(smem + pixbase[mf] + off);
 #pragma unroll
-            for (int mf = 0; mf < MFM; ++mf) {
-                if (mf < MFM - 1) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[mf], acc[mf], 0, 0, 0);
-                else if (cur.lastv) acc[MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[mf], acc[MFM - 1], 0, 0, 0);
-            }
+            for (int mf = 0; mf < MFM; ++mf)
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc) {
+                    if (mf < MFM - 1) acc[nc][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[nc], a1[mf], acc[nc][mf], 0, 0, 0);
+                    else if (cur.lastv) acc[nc][MFM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[nc], a1[mf], acc[nc][MFM - 1], 0, 0, 0);
+                }
         }
         if (!last || more) {
             __syncthreads();  // every wave is done reading this stage
@@ -369,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
             for (int mf = 0; mf < MFM; ++mf) {
                 const int p = (wp + WP * mf) * 16 + pl;
-                float v[4] = {acc[mf][0] + bv.x, acc[mf][1] + bv.y, acc[mf][2] + bv.z, acc[mf][3] + bv.w};
+                float v[4] = {acc[0][mf][0] + bv.x, acc[0][mf][1] + bv.y, acc[0][mf][2] + bv.z, acc[0][mf][3] + bv.w};
                 if (P.act) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
@@ -432,11 +451,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         return;
     }
 #ifdef OBB_DIAG
-    if (P.dbg & 2) { if (acc[0][0] != 123.456f) return; }  // timing only: no epilogue (the test keeps the accumulators alive)
+    if (P.dbg & 2) { if (acc[0][0][0] != 123.456f) return; }  // timing only: no epilogue (the test keeps the accumulators alive)
 #endif
     int plv = pl;
     if constexpr (XT) asm volatile("" : "+v"(plv));  // (opaque, as in `plan`: the pixel coordinates are recomputed per tile, not kept across the k loops)
-    const bool full = cbase + 4 <= P.cout;
+    const bool full = cbase + 4 * NC <= P.cout;
 #pragma unroll
     for (int mf = 0; mf < MFM; ++mf) {
         const int p = (wp + WP * mf) * 16 + plv;
@@ -447,31 +466,37 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         const int oy = cur.oy0 + ty, ox = cur.ox0 + tx;
         if (oy >= P.Hout || ox >= P.Wout || il >= cur.nimg) continue;
         const int64_t opix = (int64_t)oy * P.Wout + ox;
-        float v[4] = {acc[mf][0] + bv.x, acc[mf][1] + bv.y, acc[mf][2] + bv.z, acc[mf][3] + bv.w};
-        if (P.act) {
+        int64_t ob = cur.b + il, opx = opix;
+        if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }
+        float *const op0 = P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
+        const float *const rp0 = P.res ? P.res + (int64_t)(cur.b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase : nullptr;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
-        }
-        if (P.res) {
-            const float *rp = P.res + (int64_t)(cur.b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase;
-            if (full) {
-                const float4 rv = *reinterpret_cast<const float4 *>(rp);
-                v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
+        for (int nc = 0; nc < NC; ++nc) {  // (NC = 2: the two stores of a lane are 32 contiguous bytes)
+            const float4 bv = bvn[nc];
+            float v[4] = {acc[nc][mf][0] + bv.x, acc[nc][mf][1] + bv.y, acc[nc][mf][2] + bv.z, acc[nc][mf][3] + bv.w};
+            if (P.act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu32(v[j]);
+            }
+            if (rp0) {
+                const float *rp = rp0 + 4 * nc;
+                if (full) {
+                    const float4 rv = *reinterpret_cast<const float4 *>(rp);
+                    v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cbase + 4 * nc + j < P.cout) v[j] = rp[j] + v[j];
+                }
+            }
+            float *op = op0 + 4 * nc;
+            if (full && ((P.out_cs | P.out_co) & 3) == 0) {
+                *reinterpret_cast<float4 *>(op) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (cbase + j < P.cout) v[j] = rp[j] + v[j];
+                    if (cbase + 4 * nc + j < P.cout) op[j] = v[j];
             }
-        }
-        int64_t ob = cur.b + il, opx = opix;
-        if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }
-        float *op = P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
-        if (full && ((P.out_cs | P.out_co) & 3) == 0) {
-            *reinterpret_cast<float4 *>(op) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (cbase + j < P.cout) op[j] = v[j];
         }
     }
     if constexpr (!XT) return;
@@ -480,7 +505,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
     t += P.tstep;
     cur = nxt;
 #pragma unroll
-    for (int mf = 0; mf < MFM; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int mf = 0; mf < MFM; ++mf) acc[nc][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -498,9 +525,21 @@ static int c32_mfm_max(int WC) { return WC == 4 ? 7 : 4; }  // 224 / 256 / 512 p
 static int c32_mfm_min(int WC) { return WC == 4 ? 4 : (WC == 2 ? 2 : 1); }  // smallest instantiated fragment count (smaller tiles run it partly empty)
 static int c32_maxld(int ks, bool in_u8) { return in_u8 ? 3 : (ks == 1 ? 7 : 5); }
 
-Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat) {
+static Conv32Tiling plan_conv32_nc(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat, int NC, int64_t *cost_out);
+
+Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat, bool nc2) {
+    int64_t c1 = 0, c2 = 0;
+    const Conv32Tiling t1 = plan_conv32_nc(ks, stride, cin, cout, Hout, Wout, in_u8, vcat, 1, &c1);
+    if (!nc2 || in_u8 || cout < 64 || cout % 32 || t1.NI > 1 || cin < 64) return t1;  // (48-channel concats: HBM-bound, measured 4 % worse)
+    const Conv32Tiling t2 = plan_conv32_nc(ks, stride, cin, cout, Hout, Wout, in_u8, vcat, 2, &c2);
+    // (costs in MFMA groups of the busiest wave per tile; the two-fragment form may cost a few percent more of them: it reads a third less LDS)
+    return (ks == 1 || c2 * 100 <= c1 * 97) ? t2 : t1;
+}
+
+static Conv32Tiling plan_conv32_nc(int ks, int stride, int cin, int cout, int Hout, int Wout, bool in_u8, bool vcat, int NC, int64_t *cost_out) {
     Conv32Tiling t;
-    t.WC = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
+    t.NC = NC;
+    t.WC = NC == 2 ? 2 : (cout >= 64 ? 4 : (cout >= 32 ? 2 : 1));
     if (in_u8) t.CK = 4;
     else {
         // (1x1: 64-channel stages = half the barriers and LDS commits of 32: 18.40 -> 18.27 ms per 512 tiles, the 13 x 13 layers 4-6 %)
@@ -510,12 +549,15 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
         if (ks == 1 && !vcat && ck == 16 && cin % 48 == 0) ck = 48;  // 48- / 96-channel concats: one stage of three 16-channel groups instead of three stages of one k step
         t.CK = ck;
     }
-    const int WP = kNW / t.WC, MFMX = c32_mfm_max(t.WC);
+    // (NC = 2, 1x1: 3 fragments per wave = 192-pixel tiles with 64-channel stages and no spill; 4 = 256 pixels forces 32-channel stages and
+    // spills 44 bytes per lane -- same-box A/B over the forward: 17.84 ms with NC = 1, 17.59 with 4, 17.36 with 3)
+    const int WP = kNW / t.WC, MFMX = NC == 2 ? (ks == 1 ? 3 : 4) : c32_mfm_max(t.WC), MFMN = NC == 2 ? 3 : c32_mfm_min(t.WC);
     const int maxpix = 16 * WP * MFMX;
     const int chunk_cap = (vcat ? 4 : c32_maxld(ks, in_u8)) * kNW * 64;  // 16-B chunks one stage may hold
     if (ks == 1) {  // 1-D: the caller flattens batch x pixels
-        while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * c32_wfloats(1, t.CK) * 4 > 78 * 1024)) t.CK /= 2;
+        while (t.CK > 4 && (maxpix * (t.CK / 4) > chunk_cap || (int64_t)maxpix * (t.CK * 4 + 16) + t.WC * NC * c32_wfloats(1, t.CK) * 4 > 78 * 1024)) t.CK /= 2;
         t.TH = 1; t.TW = maxpix; t.MFM = MFMX; t.NI = 1;
+        if (cost_out) *cost_out = 0;
         return t;
     }
     const int PST = t.CK * 4 + 16;
@@ -525,15 +567,16 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
     int64_t best_cost = -1;
     for (int th = 1; th <= std::min(Hout, maxpix / t.TW); ++th) {
         const int64_t in_px = (int64_t)((th - 1) * stride + ks) * ((t.TW - 1) * stride + ks);
-        if (in_px * PST + t.WC * c32_wfloats(ks, t.CK) * 4 > 78 * 1024 || in_px * (in_u8 ? 1 : t.CK / 4) > chunk_cap) break;
+        if (in_px * PST + t.WC * NC * c32_wfloats(ks, t.CK) * 4 > 78 * 1024 || in_px * (in_u8 ? 1 : t.CK / 4) > chunk_cap) break;
         // time ~ tiles x (fragments of the busiest wave + the fixed cost of a stage: barriers + LDS commit, about one fragment's MFMAs)
-        const int mfm = std::max(((th * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
-        const int64_t cost = (int64_t)((Hout + th - 1) / th) * tiles_x * (mfm + 1);
+        const int mfm = std::max(((th * t.TW + 15) / 16 + WP - 1) / WP, MFMN);
+        const int64_t cost = (int64_t)((Hout + th - 1) / th) * tiles_x * (mfm * NC + 1);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_th = th; }
     }
     t.TH = best_th;
     t.NI = 1;
-    if (!in_u8 && t.TH == Hout && t.TW == Wout && Hout * Wout * 2 <= maxpix) {
+    if (cost_out) *cost_out = best_cost;
+    if (NC == 1 && !in_u8 && t.TH == Hout && t.TW == Wout && Hout * Wout * 2 <= maxpix) {
         // a small map (the 128-px scale's 8 x 8 / 4 x 4 levels): one tile = NI whole images, as many as the fragment budget, the LDS
         // tile and the staging plan take -- a tile of ONE such map would leave most of the workgroup's fragments empty
         const int64_t in1 = (int64_t)((Hout - 1) * stride + ks) * ((Wout - 1) * stride + ks);
@@ -541,7 +584,7 @@ Conv32Tiling plan_conv32(int ks, int stride, int cin, int cout, int Hout, int Wo
         while (ni > 1 && (ni * in1 * PST + t.WC * c32_wfloats(ks, t.CK) * 4 > 78 * 1024 || ni * in1 * (t.CK / 4) > chunk_cap)) --ni;
         t.NI = ni;
     }
-    t.MFM = std::max(((t.NI * t.TH * t.TW + 15) / 16 + WP - 1) / WP, c32_mfm_min(t.WC));
+    t.MFM = std::max(((t.NI * t.TH * t.TW + 15) / 16 + WP - 1) / WP, MFMN);
     return t;
 }
 
@@ -552,7 +595,7 @@ bool conv32_tail_supported(const Conv32Tiling &t, int cout1, int cout2) {
 }
 
 Conv32Tiling plan_dwpw32(int cin, int cout, int H, int W) {
-    Conv32Tiling t{0, 0, 16, 4, 0, 1};
+    Conv32Tiling t{0, 0, 16, 4, 0, 1, 1};
     if (cin % 16 || cout % 64 || W > 224) return t;
     const int WP = kNW / t.WC, maxpix = 16 * WP * c32_mfm_max(t.WC), PST = t.CK * 4 + 16;
     t.TW = W;
@@ -596,8 +639,9 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
     const int cin_eff = in_u8 ? 4 : cin;
     const int nstage = (cin_eff + CK - 1) / CK;
     const int kst = c32_kfull(ks, CK), krem = c32_krem(ks, CK);
+    const int NC = std::max(1, t.NC), nfb = t.WC * NC;  // fragments per cout block
     const int nf = (cout + 15) / 16;
-    const int nfp = (nf + t.WC - 1) / t.WC * t.WC;  // whole cout blocks
+    const int nfp = (nf + nfb - 1) / nfb * nfb;  // whole cout blocks
     const int taps = ks * ks;
     std::vector<float> out((size_t)nfp * nstage * c32_wfloats(ks, CK), 0.f);
     size_t o = 0;
@@ -606,15 +650,18 @@ std::vector<float> pack_conv32_weights(const float *w, int cout, int cin, int ks
         if (co >= cout || c >= cin || q >= taps * cpk) return 0.f;
         return w[((size_t)(perm ? perm[co] : co) * cin + c) * taps + tap];
     };
+    // cout of accumulator row r (= lane & 15) of the block's fragment f: one fragment per wave -> 16 f + r; two (NC = 2) -> the wave's 32 couts
+    // interleaved so that a lane's 4 + 4 rows (g * 4 + j of both fragments) are 8 consecutive couts: 32 (f / 2) + (r >> 2) * 8 + (f & 1) * 4 + (r & 3)
+    auto cout_of = [&](int cb, int f, int r) { return cb * nfb * 16 + (NC == 2 ? 32 * (f >> 1) + (r >> 2) * 8 + (f & 1) * 4 + (r & 3) : 16 * f + r); };
     // [cout block][stage][fragment of the block]{[piece][lane][4], [remainder chunk][lane]}: a workgroup's stage is one contiguous run
-    for (int cb = 0; cb < nfp / t.WC; ++cb)
+    for (int cb = 0; cb < nfp / nfb; ++cb)
         for (int st = 0; st < nstage; ++st)
-            for (int wc = 0; wc < t.WC; ++wc) {
+            for (int f = 0; f < nfb; ++f) {
                 for (int k = 0; k < kst; ++k)
                     for (int lane = 0; lane < 64; ++lane)
-                        for (int s = 0; s < 4; ++s) out[o++] = wat((cb * t.WC + wc) * 16 + (lane & 15), st, k * 4 + (lane >> 4), s);
+                        for (int s = 0; s < 4; ++s) out[o++] = wat(cout_of(cb, f, lane & 15), st, k * 4 + (lane >> 4), s);
                 for (int r = 0; r < krem; ++r)
-                    for (int lane = 0; lane < 64; ++lane) out[o++] = wat((cb * t.WC + wc) * 16 + (lane & 15), st, kst * 4 + r, lane >> 4);
+                    for (int lane = 0; lane < 64; ++lane) out[o++] = wat(cout_of(cb, f, lane & 15), st, kst * 4 + r, lane >> 4);
             }
     return out;
 }
@@ -628,14 +675,14 @@ size_t conv32_lds_bytes(const Conv32Launch &L) {
         return l;
     }
     const int THin = (L.TH - 1) * L.stride + L.ks, TWin = (L.TW - 1) * L.stride + L.ks;
-    size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * c32_wfloats(L.ks, L.CK) * 4;  // activation tile + stage weights
+    size_t lds = (((size_t)std::max(1, L.NI) * THin * TWin * (L.CK * 4 + 16) + 1023) & ~(size_t)1023) + (size_t)L.WC * std::max(1, L.NC) * c32_wfloats(L.ks, L.CK) * 4;  // activation tile + stage weights
     if (L.tail_cout > 0) lds = std::max(lds, (size_t)16 * (kNW / L.WC) * L.MFM * (L.cout * 4 + 16));
     return lds;
 }
 
-template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false>
+template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1>
 static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStream_t st) {
-    const void *fn = (const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>;
+    const void *fn = (const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC>;
     static bool attr_set = false;  // (per instantiation) up to 80 KiB of dynamic LDS: two workgroups per CU
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -672,7 +719,7 @@ static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStre
             grid = dim3((unsigned)(slots * 8 * P.ncb));
         }
     }
-    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW>), grid, dim3(kNW * 64), lds, st, P);
+    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC>), grid, dim3(kNW * 64), lds, st, P);
     return hipGetLastError();
 }
 
@@ -705,6 +752,19 @@ static hipError_t launch32_f(const Conv32Launch &L, const C32Params &P, int tail
 
 template <int KS>
 static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, int tail_wc2, dim3 grid, size_t lds, hipStream_t st) {
+    if (L.NC == 2) {  // two cout fragments per wave: 2 waves along cout, 3 or 4 pixel fragments per wave; plain and (1x1) VCAT forms
+        if (L.WC != 2 || tail_wc2 || L.dw || L.in_u8) return hipErrorInvalidValue;
+        if (L.up_c > 0) {
+            if constexpr (KS == 1) {
+                if (L.MFM == 4) return launch32_k<KS, 4, 2, false, true, 0, false, 2>(P, grid, lds, st);
+                if (L.MFM == 3) return launch32_k<KS, 3, 2, false, true, 0, false, 2>(P, grid, lds, st);
+            }
+            return hipErrorInvalidValue;
+        }
+        if (L.MFM == 4) return launch32_k<KS, 4, 2, false, false, 0, false, 2>(P, grid, lds, st);
+        if (L.MFM == 3) return launch32_k<KS, 3, 2, false, false, 0, false, 2>(P, grid, lds, st);
+        return hipErrorInvalidValue;
+    }
     switch (L.WC * 16 + L.MFM) {
         case 4 * 16 + 7: return launch32_f<KS, 7, 4>(L, P, tail_wc2, grid, lds, st);
         case 4 * 16 + 6: return launch32_f<KS, 6, 4>(L, P, tail_wc2, grid, lds, st);
@@ -723,7 +783,8 @@ static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, int tai
 
 hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     if (L.in.cpb || L.out.cpb || L.res.cpb || L.in2.cpb || L.tail_out.cpb) return hipErrorInvalidValue;  // plain NHWC only
-    if ((L.ks != 1 && L.ks != 3) || (L.WC != 1 && L.WC != 2 && L.WC != 4)) return hipErrorInvalidValue;
+    if ((L.ks != 1 && L.ks != 3) || (L.WC != 1 && L.WC != 2 && L.WC != 4) || (L.NC != 1 && L.NC != 2)) return hipErrorInvalidValue;
+    if (L.NC == 2 && (L.cout % 32 || L.tail_cout > 0 || L.dw || L.in_u8 || L.NI > 1)) return hipErrorInvalidValue;
     C32Params P;
     memset(&P, 0, sizeof P);
     P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
@@ -736,7 +797,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     if ((4 << P.sh) != L.CK && !(L.ks == 1 && L.CK == 48 && !L.up_c && !L.in_u8)) return hipErrorInvalidValue;
     const int WP = kNW / L.WC;
     const int NI = std::max(1, L.NI);
-    if (L.MFM < 1 || L.MFM > c32_mfm_max(L.WC) || NI * L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
+    if (L.MFM < 1 || L.MFM > (L.NC == 2 ? 4 : c32_mfm_max(L.WC)) || NI * L.TH * L.TW > 16 * WP * L.MFM || L.TH < 1 || L.TW < 1) return hipErrorInvalidValue;
     if (NI > 1 && (L.ks != 3 || L.in_u8 || L.up_c || L.tiles_x != 1 || L.tiles_y != 1 || L.TH != L.Hout || L.TW != L.Wout || L.out_hw || L.tail_out_hw)) return hipErrorInvalidValue;
     P.NI = NI; P.B = L.B; P.dw_act = L.dw_act;
     if (L.dw && (L.ks != 1 || L.stride != 1 || L.in_u8 || L.up_c || NI != 1 || L.WC != 4 || L.CK != 16 || L.out_hw || L.tail_out_hw || L.Hin != L.Hout || L.Win != L.Wout || L.TW != L.Wout ||
@@ -749,7 +810,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.kst = c32_kfull(L.ks, L.CK); P.krem = c32_krem(L.ks, L.CK); P.wcb = c32_wfloats(L.ks, L.CK) * 4;
     P.tiles_x = L.tiles_x; P.tiles_y = L.tiles_y; P.out_hw = L.out_hw;
     const int64_t ntiles = NI > 1 ? ((int64_t)L.B + NI - 1) / NI : (int64_t)L.B * L.tiles_y * L.tiles_x;
-    P.ncb = (L.cout + 16 * L.WC - 1) / (16 * L.WC);
+    P.ncb = (L.cout + 16 * L.WC * L.NC - 1) / (16 * L.WC * L.NC);
     if (ntiles < 1 || (ntiles + 7) / 8 * 8 * P.ncb >= (1ll << 31)) return hipErrorInvalidValue;
     P.ntiles = (int)ntiles;
     const int sks = L.dw ? 3 : L.ks;  // staged halo

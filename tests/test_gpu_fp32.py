@@ -105,6 +105,22 @@ def test_fp32_fused_forms_are_bit_identical(ood, nets, h, w, B):
     assert float(d0.max()) < 2e-6 * max(1.0, float(x0_plain.abs().max())) and float(d.max()) < 5e-4 and float(d.mean()) < 3e-5
 
 
+@pytest.mark.parametrize("h,w,B", [(416, 416, 5), (128, 128, 33), (416, 288, 2), (64, 96, 3), (416, 416, 40)])
+def test_fp32_two_fragment_form_is_bit_identical(ood, nets, h, w, B):
+    """`nc2`: a wave of the conv kernel owning two cout fragments x <= 4 pixel fragments (a third fewer LDS operand reads, 32-byte stores per
+    lane) against one x <= 7 -- every output still sums its k in the same order, so the heads must agree BIT FOR BIT (the weight rows are
+    permuted on the host to the interleaved cout order of the form: a wrong permutation cannot hide)."""
+    ops, net = ood.ops, nets[416]
+    x = torch.as_tensor(_tiles(11 + h + B, B, h, w)).cuda()
+    ops.model_load(net.to_blob(), precision="f32", nc2=False)
+    assert not any(" NC2 " in l for l in ops.debug_plan(h, w))
+    one = ops.forward(x).cpu()
+    ops.model_load(net.to_blob(), precision="f32")
+    assert sum(" NC2 " in l for l in ops.debug_plan(h, w)) >= 10, ops.debug_plan(h, w)
+    two = ops.forward(x).cpu()
+    assert torch.equal(one[..., :77], two[..., :77]), float((one - two)[..., :77].abs().max())
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 40), (128, 128, 600), (192, 416, 37)])
 def test_fp32_resident_workgroups_are_bit_identical(ood, nets, h, w, B):
     """`xtile`: conv workgroups that stay resident and walk several tiles (next tile's first stage fetched under this tile's last k loop)

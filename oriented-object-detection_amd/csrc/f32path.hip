@@ -336,6 +336,21 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
 #pragma unroll
                 for (int i = 0; i < H; ++i)
                     if (m0 + i < MFM) a[i] = *reinterpret_cast<const f32x4 *>(smem + pixbase[m0 + i] + off);
+#ifdef OBB_DIAG
+                if (P.dbg & 4) {  // timing only: every activation read issued twice (how sensitive is the k loop to its LDS read volume?)
+#pragma unroll
+                    for (int i = 0; i < H; ++i)
+                        if (m0 + i < MFM) { f32x4 d2 = *reinterpret_cast<const volatile f32x4 *>(smem + pixbase[m0 + i] + off); asm volatile("" ::"v"(d2)); }
+                }
+                if (P.dbg & 8) {  // timing only: no MFMAs (LDS reads + loop only)
+#pragma unroll
+                    for (int i = 0; i < H; ++i)
+                        if (m0 + i < MFM) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+                    for (int nc = 0; nc < NC; ++nc) asm volatile("" ::"v"(w[nc]));
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -846,7 +861,7 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     }
     P.tstep = L.xtile ? 1 : 0;
 #ifdef OBB_DIAG
-    { static const int dbg = getenv("OBB_C32_DBG") ? atoi(getenv("OBB_C32_DBG")) : 0; P.dbg = dbg; }  // 1: no global fetch, 2: no epilogue (timing-only ablations)
+    { static const int dbg = getenv("OBB_C32_DBG") ? atoi(getenv("OBB_C32_DBG")) : 0; P.dbg = dbg; }  // timing-only ablations: 1 no global fetch, 2 no epilogue, 4 every activation LDS read twice, 8 no MFMAs
 #endif
     const size_t lds = conv32_lds_bytes(L);
     if (lds > 80 * 1024 || P.kst > (L.ks == 3 ? 9 : 4)) return hipErrorInvalidValue;  // (kst bound: the weight-fetch plan of the kernel, MAXW)

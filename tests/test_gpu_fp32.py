@@ -121,6 +121,19 @@ def test_fp32_two_fragment_form_is_bit_identical(ood, nets, h, w, B):
     assert torch.equal(one[..., :77], two[..., :77]), float((one - two)[..., :77].abs().max())
 
 
+def test_rounds_are_sized_by_pixels_and_do_not_change_results(ood, nets):
+    """A round of the forward holds 1024 tiles of 416 x 416 or proportionally more smaller ones (at most 8192): 8200 tiles of 64 x 64 are two
+    rounds (8192 + 8); every tile's head must equal what the same tile gives in a small batch of its own."""
+    ops, net = ood.ops, nets[416]
+    ops.model_load(net.to_blob(), precision="f32")
+    B = 8200
+    x = torch.as_tensor(_tiles(99, B, 64, 64)).cuda()
+    full = ops.forward(x).clone()
+    for lo, hi in ((0, 5), (8187, 8200), (4000, 4003)):
+        part = ops.forward(x[lo:hi].contiguous())
+        assert torch.equal(full[lo:hi, :, :77], part[..., :77]), (lo, hi)
+
+
 @pytest.mark.parametrize("h,w,B", [(416, 416, 40), (128, 128, 600), (192, 416, 37)])
 def test_fp32_resident_workgroups_are_bit_identical(ood, nets, h, w, B):
     """`xtile`: conv workgroups that stay resident and walk several tiles (next tile's first stage fetched under this tile's last k loop)

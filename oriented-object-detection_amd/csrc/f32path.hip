@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 namespace obb {
 
@@ -716,6 +717,8 @@ static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStre
         // cross-tile pipeline: a grid of resident workgroups, each walking ~equally many tiles (see XT in the kernel)
         static std::map<size_t, int> occ;  // resident workgroups per CU of this instantiation, by dynamic LDS size
         static int ncu = 0;
+        static std::mutex mu;  // (contexts of different host threads launch through the same cache)
+        std::lock_guard<std::mutex> lock(mu);
         auto it = occ.find(lds);
         if (it == occ.end()) {
             int n = 0, dev = 0;

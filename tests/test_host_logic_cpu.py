@@ -58,3 +58,57 @@ def test_detset_tuple_roundtrip_cpu():
     dets = [(1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5, 3, float(np.float32(0.7)), 12.0), (0.0,) * 8 + (1, 0.25, 0.0)]
     ds = D.DetSet.from_tuples(dets, device="cpu")
     assert ds.to_tuples() == dets
+
+
+def test_export_obbw_from_an_ultralytics_shaped_module_tree():
+    """tools/export_obbw.py on a module tree with Ultralytics' structure (Conv wrappers holding `.conv` + `.act`, bare Conv2d at the head's
+    ends), built from the oracle network's records: the exported blob must carry exactly the oracle's records (names, shapes, flags, bytes)."""
+    import importlib.util
+    import os
+    import struct
+    from torch import nn
+    from conftest import ROOT
+    from oracle.yolo11_obb import Yolo11OBB
+    spec = importlib.util.spec_from_file_location("export_obbw", os.path.join(ROOT, "tools", "export_obbw.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    net = Yolo11OBB("n", nc=12, ch=3, seed=5)
+
+    class Wrap(nn.Module):  # ultralytics.nn.modules.conv.Conv after fuse(): conv (with bias) + act, the bn attribute deleted
+        def __init__(self, conv, act):
+            super().__init__()
+            self.conv, self.act = conv, (nn.SiLU() if act else nn.Identity())
+
+    root = nn.Module()
+    for r in net.convs.values():
+        conv = nn.Conv2d(r.c1, r.c2, r.k, r.s, r.k // 2, groups=r.g, bias=True)
+        with torch.no_grad():
+            conv.weight.copy_(r.w)
+            conv.bias.copy_(r.b)
+        # the head's last 1x1 of each branch is a bare Conv2d in Ultralytics; everything else a Conv wrapper (also the act=False ones)
+        bare = r.name.startswith("model.23.") and r.name.endswith(".2")
+        leaf = conv if bare else Wrap(conv, r.act)
+        parent, parts = root, r.name.split(".")
+        for p in parts[:-1]:
+            if not hasattr(parent, p):
+                parent.add_module(p, nn.Module())
+            parent = getattr(parent, p)
+        parent.add_module(parts[-1], leaf)
+    blob = ex.blob_from_module(root, 12, "n")
+    ref = net.to_blob()
+
+    def parse(b):
+        magic, ver, nrec, nc, ch, width, depth, max_ch, reg_max = struct.unpack_from("<4sIIiiffii", b, 0)
+        scale = struct.unpack_from("<8s", b, 36)[0].rstrip(b"\0")
+        out, o = {}, 44
+        for _ in range(nrec):
+            name, c1, c2, k, s, g, act, w0, b0 = struct.unpack_from("<64siiiiiiQQ", b, o)
+            o += 64 + 6 * 4 + 2 * 8
+            out[name.rstrip(b"\0").decode()] = (c1, c2, k, s, g, act, b[w0:b0], b[b0:b0 + 4 * c2])
+        return (magic, ver, nrec, nc, ch, width, depth, max_ch, reg_max, scale), out
+    h1, r1 = parse(blob)
+    h2, r2 = parse(ref)
+    assert h1 == h2
+    assert r1.keys() == r2.keys()
+    for k in r2:
+        assert r1[k] == r2[k], k

@@ -96,7 +96,10 @@ int obb_nms_mask(obb_ctx *ctx, const double *boxes_sorted, const int32_t *cls_so
                  uint64_t *mask, obb_stream_t s);
 /* Greedy scan of that matrix (Detect_OBB.py:186-198): keep[i] in sorted order, *n_keep = number kept. */
 int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
-/* The whole function: sort + mask + scan.  order[n] (sorted position -> input index), keep[n] (sorted order). */
+/* The whole function: sort + suppression pairs + greedy scan.  order[n] (sorted position -> input index), keep[n] (sorted order).
+ * No host read and no synchronisation at any n: the choice between the sparse pair list and the matrix-free dense scan (pair-list
+ * overflow, thr <= 0) is taken on the device, so the call can be captured into a hipGraph once its workspaces exist (call it once
+ * eagerly at the largest n first).  n <= 1.2 M rows. */
 int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n,
                          double thr, int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
 /* Batched form for the per-tile call at Detect_OBB.py:264: nseg independent segments, segment k owning rows
@@ -175,7 +178,7 @@ int obb_rotated_tal_assign(obb_ctx *ctx, const float *pd_scores, const float *pd
 /* ------------------------------------------------------------------ training step, slice 3 */
 /* Backward of a stride-1 convolution with `same` padding (k = 1 or 3), bf16 NHWC tensors, fp32 accumulation (Train_OBB.py:796-841: bf16
  * autocast over fp32 master weights).  dgrad: dy bf16[B][H][W][cout] (device), w fp32[cout][cin][k][k] (HOST: repacked per call into
- * the MFMA fragment order of the forward kernel) -> dx bf16[B][H][W][cin].  wgrad: x bf16[B][H][W][cin], dy -> dw fp32[cout][cin][k][k]
+ * the MFMA fragment order of the forward kernel; (synchronises)) -> dx bf16[B][H][W][cin].  wgrad: x bf16[B][H][W][cin], dy -> dw fp32[cout][cin][k][k]
  * (device), cin and cout multiples of 64; deterministic (fixed summation order). */
 int obb_conv_dgrad_bf16(obb_ctx *ctx, const uint16_t *dy, const float *w_oihw_host, int32_t B, int32_t H, int32_t W, int32_t cin,
                         int32_t cout, int32_t ks, uint16_t *dx, obb_stream_t s);

@@ -10,6 +10,7 @@
 // All of this is byte/compare work on KB..MB inputs: the kernels are HBM/latency bound, so the design rules are
 // coalesced SoA streams, LDS-resident segments, wave64 ballots/shuffles for the serial scans, and no GEMM shaping.
 #include <algorithm>
+#include <mutex>
 
 #include "ctx.h"
 #include "geom_device.h"
@@ -525,13 +526,14 @@ __global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sbox
 // The graph is a DAG ordered by index, so relaxing all undecided nodes in parallel reaches the greedy fixed point of
 // Detect_OBB.py:186-198 in (longest suppression chain) rounds.  Single workgroup; node states live in LDS, 1 byte each:
 // bits 0-1 = state (0 undecided, 1 keep, 2 drop), bit 2 = "a kept predecessor seen", bit 3 = "an undecided predecessor seen".
-__global__ __launch_bounds__(1024) void k_nms_resolve(const unsigned long long *__restrict__ edges, const unsigned int *__restrict__ edge_count,
+__global__ __launch_bounds__(1024) void k_nms_resolve(const unsigned long long *__restrict__ edges, const unsigned int *__restrict__ edge_count, unsigned int edge_cap,
                                                      int64_t n, uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep) {
     extern __shared__ unsigned int st_words[];  // ceil(n/4) words
     __shared__ int undecided_s, total_s;
     const int tid = threadIdx.x;
     const int nw = (int)((n + 3) / 4);
     const unsigned int E = *edge_count;
+    if (E > edge_cap) return;  // the pair list overflowed (edges past the capacity were dropped): k_nms_lazy, launched right behind, takes over
     for (int w = tid; w < nw; w += 1024) st_words[w] = 0u;
     if (tid == 0) total_s = 0;
     __syncthreads();
@@ -615,6 +617,83 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const unsigned long long *_
         __syncthreads();
     }
     if (threadIdx.x == 0 && n_keep) *n_keep = total_s;
+}
+
+// Greedy scan WITHOUT a stored pair matrix: the fall-back of the sparse form for the inputs it cannot take -- a pair list that overflowed its
+// capacity (more than 64 n + 4096 suppressing pairs: piles of near-identical boxes), thr <= 0 (every same-class pair suppresses), or more rows
+// than k_nms_resolve's LDS states hold.  Predicated on the DEVICE (`force`, or *edge_count > edge_cap): the host launches it unconditionally
+// behind k_nms_resolve and never reads the pair count, so obb_merge_detections has no host synchronisation and can be stream-captured.
+// One workgroup walks the rows in blocks of 64 (sorted order): (1) the block's 64 x 64 upper-triangular pair tests (two per thread) -> 64
+// suppression words in LDS; (2) wave 0 resolves the block serially against `removed` (as k_nms_reduce does); (3) all 1024 threads test
+// the not-yet-removed later rows against the block's KEPT rows only and mark the hits in `removed` (1 bit per row, LDS: n <= 1.2 M).
+// Same pair predicate as k_nms_mask / k_grid_pairs (class, envelope, exact IoU with the earlier row as first operand), so the result is
+// the same greedy fixed point; the cost is kept-rows x later-rows cheap tests, paid only by the rare inputs named above.
+__global__ __launch_bounds__(1024) void k_nms_lazy(const double *__restrict__ sboxes, const int32_t *__restrict__ scls, const BoxMeta *__restrict__ meta, int64_t n,
+                                                  double thr, const unsigned int *__restrict__ edge_count, unsigned int edge_cap, int force,
+                                                  uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep) {
+    if (!force && *edge_count <= edge_cap) return;
+    extern __shared__ unsigned long long removed[];  // ceil(n / 64) words
+    __shared__ BoxMeta bm[64];
+    __shared__ int32_t bc[64];
+    __shared__ double bq[64][8];
+    __shared__ unsigned long long diag[64];
+    __shared__ unsigned long long keepmask_s;
+    __shared__ int total_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = (int)((n + 63) / 64);
+    const bool all_hit = !(thr > 0.0);
+    for (int w = tid; w < W; w += 1024) removed[w] = 0ull;
+    if (tid == 0) total_s = 0;
+    __syncthreads();
+    auto hit = [&](int r, const BoxMeta &mj, int32_t cj, int64_t j) -> bool {  // does block row r (earlier) suppress row j?
+        if (bc[r] != cj) return false;
+        if (all_hit) return true;
+        if (!meta_overlap(bm[r], mj)) return false;
+        P2 a[4], b[4];
+        for (int k = 0; k < 4; ++k) { a[k].x = bq[r][2 * k]; a[k].y = bq[r][2 * k + 1]; b[k].x = sboxes[j * 8 + 2 * k]; b[k].y = sboxes[j * 8 + 2 * k + 1]; }
+        return poly_iou_core(a, b) >= thr;
+    };
+    for (int rb = 0; rb < W; ++rb) {
+        const int64_t i0 = (int64_t)rb * 64;
+        const int nvalid = (int)((n - i0) < 64 ? (n - i0) : 64);
+        if (tid < 64) {
+            const int64_t i = i0 + tid;
+            if (tid < nvalid) { bm[tid] = meta[i]; bc[tid] = scls[i]; } else { bm[tid].x0 = 1.0; bm[tid].x1 = -1.0; bm[tid].y0 = 1.0; bm[tid].y1 = -1.0; bc[tid] = -2; }
+            diag[tid] = 0ull;
+        }
+        if (tid < 512) { const int r = tid >> 3, q = tid & 7; bq[r][q] = r < nvalid ? sboxes[(i0 + r) * 8 + q] : 0.0; }
+        __syncthreads();
+        for (int pidx = tid; pidx < 64 * 64; pidx += 1024) {  // pairs (r < c) inside the block
+            const int r = pidx >> 6, c = pidx & 63;
+            if (r < c && c < nvalid && hit(r, bm[c], bc[c], i0 + c)) atomicOr(&diag[r], 1ull << c);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long d = diag[lane];
+            unsigned long long rem = removed[rb], km = 0ull;
+            for (int r = 0; r < nvalid; ++r) {
+                const unsigned long long dr = __shfl(d, r);  // wave-uniform
+                if (!((rem >> r) & 1ull)) { km |= 1ull << r; rem |= dr; }
+            }
+            if (lane < nvalid) keep[i0 + lane] = (uint8_t)((km >> lane) & 1ull);
+            if (lane == 0) { keepmask_s = km; total_s += __popcll(km); }
+        }
+        __syncthreads();
+        const unsigned long long km = keepmask_s;
+        for (int64_t j = i0 + 64 + tid; j < n; j += 1024) {
+            if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
+            const BoxMeta mj = meta[j];
+            const int32_t cj = scls[j];
+            unsigned long long w = km;
+            while (w) {
+                const int r = __ffsll((long long)w) - 1;
+                w &= w - 1;
+                if (hit(r, mj, cj, j)) { atomicOr(&removed[j >> 6], 1ull << (j & 63)); break; }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && n_keep) *n_keep = total_s;
 }
 
 // ------------------------------------------------------------------------------------------------ LDS-resident segments (n <= kSegMax)
@@ -1228,6 +1307,10 @@ __global__ __launch_bounds__(256) void k_gather_compact(const int32_t *__restric
     reinterpret_cast<int4 *>(out + (int64_t)before * 12)[i] = src[i];
 }
 
+__global__ void k_set_segment(int32_t *segoff, int32_t n, int32_t *status) {
+    if (threadIdx.x == 0) { segoff[0] = 0; segoff[1] = n; status[0] = 0; }
+}
+
 __global__ void k_add_offset(int32_t *v, int64_t n, int32_t add) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] += add;
@@ -1430,9 +1513,7 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         int32_t *segoff = (int32_t *)ctx->workspace(WS_GEOM_D, 256);
         int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
         if (!segoff || !status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
-        int32_t h[2] = {0, (int32_t)n};
-        OBB_HIP(ctx, hipMemcpyAsync(segoff, h, sizeof h, hipMemcpyHostToDevice, st));
-        OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_set_segment, dim3(1), dim3(64), 0, st, segoff, (int32_t)n, status);  // (a kernel, not a host copy: capturable, no host memory referenced at replay)
         hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
@@ -1448,14 +1529,27 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
     hipLaunchKernelGGL(k_prep_sorted, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, boxes, cls, (const int32_t *)order, n, sboxes,
                        scls, meta);
     OBB_LAUNCH_CHECK(ctx);
-    // sparse form: suppression pairs as an edge list + parallel DAG relaxation (node states in LDS: n <= 600k)
+    // sparse form: suppression pairs as an edge list + parallel DAG relaxation (node states in LDS: n <= 600k).  The dense fall-back
+    // (k_nms_lazy) is predicated on the device: no host read of the pair count, no synchronisation -- the call is capturable.
     const size_t lds_states = (size_t)cdiv(n, 4) * 4;
-    if (thr > 0.0 && lds_states <= 150 * 1024) {
-        const unsigned int cap = (unsigned int)std::min<int64_t>(64 * n + 4096, 1ll << 28);
+    const size_t lds_lazy = (size_t)W * 8 + 64;
+    OBB_REQUIRE(ctx, lds_lazy <= 150 * 1024, "obb_merge_detections: n=%lld exceeds the 1.2M rows the LDS-resident scans hold", (long long)n);
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute((const void *)k_nms_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void *)k_nms_lazy, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
+    OBB_HIP(ctx, attr_err);
+    unsigned int *ecount = (unsigned int *)ctx->workspace(WS_NMS_D, 256);
+    if (!ecount) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
+    OBB_HIP(ctx, hipMemsetAsync(ecount, 0, sizeof(unsigned int), st));
+    const bool sparse = thr > 0.0 && lds_states <= 150 * 1024;
+    unsigned int cap = 0;
+    if (sparse) {
+        cap = (unsigned int)std::min<int64_t>(64 * n + 4096, 1ll << 28);
         unsigned long long *edges = (unsigned long long *)ctx->workspace(WS_NMS_C, sizeof(unsigned long long) * (size_t)cap);
-        unsigned int *ecount = (unsigned int *)ctx->workspace(WS_NMS_D, 256);
-        if (!edges || !ecount) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
-        OBB_HIP(ctx, hipMemsetAsync(ecount, 0, sizeof(unsigned int), st));
+        if (!edges) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
         if (n >= kGridMin) {  // candidate partners through a uniform grid instead of all pairs
             const int ncell = kGridDim * kGridDim;
             int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * (2 * (size_t)n + 2 * (size_t)ncell + 64));
@@ -1473,27 +1567,12 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
             hipLaunchKernelGGL(k_nms_mask<true>, dim3((unsigned)W, (unsigned)W), dim3(64), 0, st, (const double *)sboxes, (const int32_t *)scls,
                                (const BoxMeta *)meta, n, thr, (unsigned long long *)nullptr, edges, ecount, cap);
         }
-        OBB_LAUNCH_CHECK(ctx);
-        unsigned int E = 0;
-        OBB_HIP(ctx, hipMemcpyAsync(&E, ecount, sizeof E, hipMemcpyDeviceToHost, st));
-        OBB_HIP(ctx, hipStreamSynchronize(st));  // the pair count decides between the sparse and the dense scan
-        if (E <= cap) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                OBB_HIP(ctx, hipFuncSetAttribute((const void *)k_nms_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_nms_resolve, dim3(1), dim3(1024), lds_states, st, (const unsigned long long *)edges, (const unsigned int *)ecount, n,
-                               keep, n_keep);
-            OBB_LAUNCH_CHECK(ctx);
-            return OBB_OK;
-        }
+        hipLaunchKernelGGL(k_nms_resolve, dim3(1), dim3(1024), lds_states, st, (const unsigned long long *)edges, (const unsigned int *)ecount, cap, n, keep, n_keep);
     }
-    uint64_t *mask = (uint64_t *)ctx->workspace(WS_NMS_B, sizeof(uint64_t) * (size_t)(W * n));
-    if (!mask) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
-    rc = nms_mask_impl(ctx, sboxes, scls, meta, n, thr, mask, st);
-    if (rc) return rc;
-    return obb_nms_reduce(ctx, mask, n, keep, n_keep, s);
+    hipLaunchKernelGGL(k_nms_lazy, dim3(1), dim3(1024), lds_lazy, st, (const double *)sboxes, (const int32_t *)scls, (const BoxMeta *)meta, n, thr,
+                       (const unsigned int *)ecount, cap, sparse ? 0 : 1, keep, n_keep);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
 }
 
 int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int64_t *off_host,

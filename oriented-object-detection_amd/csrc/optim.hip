@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void k_sgd_step(float *__restrict__ p, const f
     if (i4 + 4 <= n) {
         float4 pv = *reinterpret_cast<const float4 *>(p + i4);
         const float4 gv = *reinterpret_cast<const float4 *>(g + i4);
-        float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(buf + i4);
+        // (momentum 0: `buf` may be NULL -- include/obbhip.h: "no buffer touched")
+        float4 bv = (first || mu == 0.f) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(buf + i4);
         float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

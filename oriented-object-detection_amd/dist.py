@@ -3,8 +3,8 @@
 Tiles are independent through forward / decode / Fast-NMS / border filter / per-tile merge (Detect_OBB.py:216-264 has
 no cross-tile state), so the tile list is sharded across ranks with no data-path collective.  Only the fusion steps
 (:290-291) need every detection of an image: survivors are exchanged once per image as fixed 48-byte records in ONE
-fixed-capacity all-gather (row 0 of every rank's buffer carries its count, written on the device; KB- to MB-scale,
-latency-bound, a single step), compacted by one kernel (obb_gather_compact) whose small count tensor is the step's one host
+fixed-capacity all-gather (row 0 of every rank's buffer carries its count, written on the device; (capacity + 1) x 48 B per rank:
+0.2 MB at the starting capacity, 0.8 MB per rank at the bench's 16 384 -- 6.3 MB gathered at 8 ranks; a single step), compacted by one kernel (obb_gather_compact) whose small count tensor is the step's one host
 read, after which every rank holds the identical, tile-ordered record list and runs the fusion replicated.
 RCCL itself has not been executed yet (no multi-GPU box was available to the builder): the exchange is covered by 2-rank gloo
 tests on CPU and a 2-rank gloo rehearsal on one MI355X.
@@ -28,9 +28,11 @@ def all_gather_records(rec, group=None, capacity=None):
     buffer whose row 0 carries its record count (written on the device: the local count is never read by the host).  After the
     collective one kernel (obb_gather_compact) packs the valid rows of all ranks densely, in rank order == tile order for contiguous
     shards, and leaves the per-rank counts + their total in one small tensor: that tensor is the single host read of the step.
-    `capacity` (records per rank) must be the same on every rank: by default it is sticky per process group -- it starts at 16384 (or
-    `capacity`) and, when some rank's count exceeds it (every rank sees the same counts, so every rank takes this branch), doubles to
-    the next power of two for a second exchange and for all later steps.  Nothing is ever truncated."""
+    The capacity (records per rank) must be the same on every rank: by default it is sticky per process group (keyed by the group's
+    global-rank tuple, so a later group with a recycled Python id never inherits it) -- it starts at 4096 and, when some rank's count
+    exceeds it (every rank sees the same counts, so every rank takes this branch), grows to the next power of two for a second exchange
+    and for all later steps.  An explicit `capacity` (tests) is checked for equality across the ranks with one small all-reduce before it
+    is used.  Unused rows are zeros, never uninitialised memory.  Nothing is ever truncated."""
     from . import ops
     world = dist.get_world_size(group)
     if world == 1:
@@ -39,11 +41,18 @@ def all_gather_records(rec, group=None, capacity=None):
     nccl = dist.get_backend(group) == "nccl"
     packed = rec.packed if rec.packed is not None else rec.pack()          # [rows >= n, 12] on the device
     n_dev = rec.count if rec.count is not None else torch.tensor([len(rec)], dtype=torch.int32, device=dev)
-    key = id(group) if group is not None else 0
-    cap = int(capacity) if capacity else _CAPACITY.get(key, 16384)
+    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    if capacity:
+        cap = int(capacity)
+        lohi = torch.tensor([cap, -cap], dtype=torch.int64, device=dev if nccl else "cpu")
+        dist.all_reduce(lohi, op=dist.ReduceOp.MAX, group=group)
+        if int(lohi[0]) != cap or int(lohi[1]) != -cap:
+            raise ValueError(f"all_gather_records: capacity differs between ranks (this rank {cap}, max {int(lohi[0])}, min {-int(lohi[1])})")
+    else:
+        cap = _CAPACITY.get(key, _CAPACITY_START)
 
     def exchange(cap):
-        send = torch.empty((cap + 1, 12), dtype=torch.int32, device=dev)
+        send = torch.zeros((cap + 1, 12), dtype=torch.int32, device=dev)
         send[0, 0:1] = n_dev                                               # device-to-device: no host read of the local count
         m = min(cap, packed.shape[0])
         send[1:1 + m] = packed[:m]                                         # rows past the count are never looked at by the receiver
@@ -74,7 +83,8 @@ def all_gather_records(rec, group=None, capacity=None):
     return out
 
 
-_CAPACITY = {}  # process group -> sticky capacity (records per rank)
+_CAPACITY = {}  # global ranks of the process group -> sticky capacity (records per rank)
+_CAPACITY_START = 4096
 
 
 def detect_symbols_distributed(image, model, tile_size, overlap, cfg=DEFAULT, conf=None, batch=256, group=None):

@@ -1,7 +1,8 @@
 """N > 1 path end to end on the GPU box: two ranks (gloo rendezvous on 127.0.0.1, both on the one card of the box -- RCCL needs one GPU per
 rank, which the 1-GPU box does not have) run process_image_distributed on the same image: sharded tile lists, ONE fixed-capacity
 record exchange per scale with the counts kept on the device, device-side compaction, replicated fusion.  Every rank must end with
-exactly the detections the single-process process_image_device produces."""
+exactly the detections the single-process process_image_device produces; the same for a 4-channel checkpoint with sharded tiles
+(BASELINE configs[3]: the DT-edge channel is built per rank for its own tiles)."""
 import os
 import socket
 import subprocess
@@ -30,10 +31,17 @@ WORKER = textwrap.dedent('''
     ok = True
     for capacity in (None, 8):  # 8: smaller than a shard's survivor count -> the second, larger exchange
         if capacity:
-            DD._CAPACITY.clear(); DD._CAPACITY[0] = capacity
+            DD._CAPACITY.clear(); DD._CAPACITY_START = capacity
         got = DD.process_image_distributed(img, models).to_tuples()
         exp = D.process_image_device(img, models)["merged_for_pr"].to_tuples()
         ok = ok and len(exp) > 3 and got == exp
+    # BASELINE configs[3] as written: a 4-channel (RGB + DT-edge) checkpoint with the tile list SHARDED -- every rank builds the edge channel of
+    # its own tiles only (build_multich per crop: Detect_OBB.py:95-133 has no cross-tile state), then the same exchange and replicated merge
+    DD._CAPACITY.clear(); DD._CAPACITY_START = 4096
+    m4 = YOLO(Yolo11OBB("n", nc=12, ch=4, seed=2), imgsz=416)
+    got4 = DD.detect_symbols_distributed(img, m4, 416, 100).to_tuples()
+    exp4 = D.detect_symbols_device(img, m4, 416, 100).to_tuples()
+    ok = ok and len(exp4) > 3 and got4 == exp4
     flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     sys.exit(0 if int(flag.item()) == 1 else 3)

@@ -468,6 +468,23 @@ def test_registered_ops_and_torch_cuda_graph(ops, net_n):
     exp_head = ops.forward(x2)
     exp_det, exp_cnt = ops.decode_nms(exp_head, h, w, 0.25, 0.7, 300)
     assert torch.equal(head, exp_head) and torch.equal(cnt, exp_cnt) and torch.equal(det, exp_det)
+    # obb_merge_detections has no host read at any n (the sparse / dense decision is taken on the device): captured at three sizes -- the
+    # LDS-resident segment kernel, the all-pairs edge list, the grid pair search -- and replayed on new boxes
+    import synth
+    for n in (300, 2000, 9000):
+        b1, c1, s1, _ = synth.make_dets(n, n, extent=60.0 * n ** 0.5)
+        b2, c2, s2, _ = synth.make_dets(n + 1, n, extent=60.0 * n ** 0.5)
+        Bt, Ct, St = torch.tensor(b1).cuda(), torch.tensor(c1).cuda(), torch.tensor(s1).cuda()
+        order, keep, nk = ops.merge_detections(Bt, Ct, St, 0.4)  # eager first: workspaces and function attributes exist before the capture
+        gm = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gm):
+            torch.ops.obbhip.merge_detections(Bt, Ct, St, 0.4, order, keep, nk)
+        Bt.copy_(torch.tensor(b2)); Ct.copy_(torch.tensor(c2)); St.copy_(torch.tensor(s2))
+        order.zero_(); keep.zero_(); nk.zero_()
+        gm.replay()
+        torch.cuda.synchronize()
+        eo, ek, enk = ops.merge_detections(Bt, Ct, St, 0.4)
+        assert torch.equal(order, eo) and torch.equal(keep, ek) and torch.equal(nk, enk) and 0 < int(nk.item()) < n, n
 
 
 def test_model_slots_are_released(ops):

@@ -107,6 +107,32 @@ def test_merge_dense_path_vs_oracle(ops, n, extent):
     assert np.array_equal(k2.cpu().numpy(), ek)
 
 
+@pytest.mark.parametrize("case", ["pile", "thr0", "thr0_grid", "pile_grid"])
+def test_merge_matrix_free_dense_scan(ops, case):
+    """the device-predicated fall-back of the sparse pair list (k_nms_lazy): (a) a pair list that overflows its 64 n + 4096 entries -- piles of
+    near-identical same-class boxes, (b) thr <= 0 where every same-class pair suppresses (Detect_OBB.py:193: IoU >= thr always holds) -- must
+    give the oracle's keep flags, below and above the grid pair search's threshold of 8192 rows; no host read decides between the paths."""
+    rng = np.random.default_rng(21)
+    if case in ("pile", "pile_grid"):
+        n = 3000 if case == "pile" else 9000
+        base, _, _, _ = synth.make_dets(5, 6, extent=300.0)
+        boxes = base[rng.integers(0, 6, n)] + rng.normal(0, 0.05, (n, 8))  # six piles of ~n/6 near-identical boxes each: ~n^2/12 pairs
+        cls = np.zeros(n, np.int32)
+        thr = 0.4
+    else:
+        n = 2500 if case == "thr0" else 8500
+        boxes, cls, _, _ = synth.make_dets(6, n, extent=3000.0)
+        thr = 0.0
+    conf = rng.uniform(0.25, 1, n).astype(np.float32).astype(np.float64)
+    eo, ek = og.merge_arrays(boxes, cls, conf, thr)
+    order, keep, nk = ops.merge_detections(dev(boxes, torch.float64), dev(cls, torch.int32), dev(conf, torch.float64), thr)
+    assert np.array_equal(order.cpu().numpy(), eo)
+    assert np.array_equal(keep.cpu().numpy(), ek)
+    assert int(nk.item()) == int(ek.sum())
+    if thr == 0.0:
+        assert int(ek.sum()) == len(np.unique(cls))  # one survivor per class
+
+
 def test_merge_idempotent_at_scale(ops):
     """size-independent property at a size the oracle is too slow for: merging the survivors again changes nothing."""
     n = 65536

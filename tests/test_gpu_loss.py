@@ -235,6 +235,21 @@ def test_optimizer_steps_match_torch_optim(n, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 4, 1027])
+def test_sgd_step_c_abi_null_momentum_buffer(n):
+    """include/obbhip.h: "momentum 0: no buffer touched" -- a C caller may pass momentum_buf = NULL with first_step = 0 (the Python wrapper
+    always hands over a real buffer, so this goes through the C-ABI directly)."""
+    import oriented_object_detection_amd  # noqa: F401
+    from oriented_object_detection_amd import ops
+    p = torch.arange(n, dtype=torch.float32).cuda()
+    g = torch.ones(n, dtype=torch.float32).cuda()
+    c = ops.ctx(p.device)
+    ops._call("obb_sgd_step", c, ops._p(p), ops._p(g), None, n, 0.5, 0.0, 0.0, 0, 0, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(p.cpu(), torch.arange(n, dtype=torch.float32) - 0.5)
+
+
+@pytest.mark.gpu
 def test_flat_optimizer_views_receive_gradients():
     import oriented_object_detection_amd.train as TR
     shapes = [(16, 8, 3, 3), (16,), (5, 7)]

@@ -38,6 +38,7 @@ struct Buf {
     bool virt = false;  // virtual concat [nearest-x2 upsample of va | vb]: never materialised, read in place by a 1x1 conv (ConvLaunch::up_c)
     int va_buf = -1, va_co = 0, va_C = 0, vb_buf = -1, vb_co = 0, vb_C = 0;
     int blk = 0;  // > 0: channel-blocked layout [C / blk][image][pixel][blk] (TensorRef::cpb); 0 = plain NHWC
+    int blk32 = 0;  // fp32 mode, 8: per-image channel blocks [image][C / 8][pixel][8] (f32path.hip C32Params): written by a conv, read by 3x3 / depthwise-prologue / virtual-concat-skip launches only
     std::string name;
     int64_t off = 0;  // byte offset into the slab per image-capacity unit (resolved at allocation)
     void *p = nullptr;
@@ -188,10 +189,11 @@ struct Builder {
     int ch(int c) const { return make_divisible(std::min(c, M.max_ch) * (double)M.width, 8); }
     int reps(int n) const { return n > 1 ? std::max((int)std::lround(n * (double)M.depth), 1) : n; }
 
-    int buf(int H, int W, int C, const std::string &name, bool f32 = false, int blk = 0) {
+    int buf(int H, int W, int C, const std::string &name, bool f32 = false, int blk = 0, bool blk32 = false) {
         Buf b;
         b.H = H; b.W = W; b.C = C; b.f32 = f32 || M.f32; b.name = name;
         if (!M.f32 && blk >= 16 && (blk & (blk - 1)) == 0 && C % blk == 0 && C > blk) b.blk = blk;
+        if (M.f32 && blk32 && M.o.blk32 && M.tail && C % 8 == 0 && C > 8) b.blk32 = 8;
         P.bufs.push_back(b);
         return (int)P.bufs.size() - 1;
     }
@@ -330,6 +332,14 @@ struct Builder {
             P.named[name] = out;
             return;
         }
+        if (M.f32 && !in_u8 && !op.vin && P.bufs[in.buf].blk32 && r->k != 3) {
+            err = set_error(ctx, OBB_ERR_STATE, "layer %s cannot read the channel-blocked buffer '%s'", name.c_str(), P.bufs[in.buf].name.c_str());
+            return;
+        }
+        if (M.f32 && ((res.C && P.bufs[res.buf].blk32) || (tail_name && out.buf >= 0 && P.bufs[out.buf].blk32))) {
+            err = set_error(ctx, OBB_ERR_STATE, "layer %s: residual / fused-1x1 output in a channel-blocked buffer", name.c_str());
+            return;
+        }
         if (M.f32) {  // fp32-arithmetic mode: exact-f32 MFMA kernels (f32path.hip)
             op.type = OP_CONV32;
             Conv32Launch &L = op.c32;
@@ -432,6 +442,7 @@ struct Builder {
             err = set_error(ctx, OBB_ERR_FORMAT, "record %s: not a depthwise 3x3 matching the graph", name.c_str());
             return;
         }
+        if (M.f32 && (P.bufs[in.buf].blk32 || P.bufs[out.buf].blk32)) { err = set_error(ctx, OBB_ERR_STATE, "depthwise layer %s on a channel-blocked buffer", name.c_str()); return; }
         int C = in.C;
         std::vector<bf16_t> w((size_t)9 * C + 8, 0);
         std::vector<float> b((size_t)C + 8, 0.f);
@@ -745,7 +756,9 @@ struct Builder {
         }
         int cat19 = buf(H16, W16, c256 + c512, "cat19");   // [x17, x13]
         int cat22 = buf(H32, W32, c512 + c1024, "cat22");  // [x20, x10]
-        Slice x4 = fold ? whole(buf(H8, W8, c512, "x4")) : sub(cat16, c512, c512), x6 = fold ? whole(buf(H16, W16, c512, "x6")) : sub(cat13, c1024, c512);
+        // fp32 mode: tensors whose consumers are 3x3 convs in 8- / 16-channel stages (stride-2 backbone convs, first head convs), depthwise
+        // prologues or the skip half of a virtual concat live in 8-channel blocks per image (Buf::blk32): a stage then reads dense runs
+        Slice x4 = fold ? whole(buf(H8, W8, c512, "x4", false, 0, true)) : sub(cat16, c512, c512), x6 = fold ? whole(buf(H16, W16, c512, "x6", false, 0, true)) : sub(cat13, c1024, c512);
         Slice x10 = sub(cat22, c512, c1024), x13 = sub(cat19, c256, c512);
 
         const bool t1 = tail16_ok("model.1", "model.2.cv1", H2, W2), t3 = tail16_ok("model.3", "model.4.cv1", H4, W4);
@@ -754,7 +767,7 @@ struct Builder {
         if (!use_front) conv("model.0", Slice{-1, 0, M.ch}, h, w, whole(b0));
         int b1 = t1 ? -1 : buf(H4, W4, c128, "x1");
         if (!t1) conv("model.1", whole(b0), H2, W2, whole(b1));
-        int b2 = buf(H4, W4, c256, "x2", false, 16);  // consumed by a 3x3 stride-2 conv in 16-channel stages
+        int b2 = buf(H4, W4, c256, "x2", false, 16, true);  // consumed by a 3x3 stride-2 conv in 16-channel (fp32: 8-channel) stages
         if (t1) c3k2(2, Slice(), H4, W4, whole(b2), n2, big, 0.25, "model.1", use_front ? Slice{-1, 0, c64} : whole(b0), H2, W2);
         else c3k2(2, whole(b1), H4, W4, whole(b2), n2, big, 0.25);
         int b3 = t3 ? -1 : buf(H8, W8, c256, "x3");
@@ -813,11 +826,13 @@ struct Builder {
         c3k2(13, whole(cat13), H16, W16, x13, n2, big, 0.5);
         if (fold) cat16 = vbuf(H8, W8, x13, x4, "cat16");
         else upsample(x13, H16, W16, sub(cat16, 0, c512));
-        int b16 = buf(H8, W8, c256, "x16");
+        // (the pyramid levels are also read by the class branch's depthwise conv: blocked only where that runs as a prologue (dwpw32))
+        auto feat_blk = [&](int C, int H, int W) { return M.f32 && M.tail && M.o.dwpw && plan_dwpw32(C, std::max(c256, std::min(M.nc, 100)), H, W).TH > 0; };
+        int b16 = buf(H8, W8, c256, "x16", false, 0, feat_blk(c256, H8, W8));
         c3k2(16, whole(cat16), H8, W8, whole(b16), n2, big, 0.5);
         P.ops.back().signal_feat = 0;
         conv("model.17", whole(b16), H8, W8, sub(cat19, 0, c256));
-        int b19 = buf(H16, W16, c512, "x19");
+        int b19 = buf(H16, W16, c512, "x19", false, 0, feat_blk(c512, H16, W16));
         c3k2(19, whole(cat19), H16, W16, whole(b19), n2, big, 0.5);
         P.ops.back().signal_feat = 1;
         conv("model.20", whole(b19), H16, W16, sub(cat22, 0, c512));
@@ -864,7 +879,7 @@ struct Builder {
                 mark_branch(first_op, 1, i);
                 continue;
             }
-            t1 = buf(Hs[i], Ws[i], c2, p + ".t1");
+            t1 = buf(Hs[i], Ws[i], c2, p + ".t1", false, 0, true);
             conv(p + ".0", whole(feats[i]), Hs[i], Ws[i], whole(t1));
             if (tail_ok(p + ".1", p + ".2", Hs[i], Ws[i])) {
                 conv(p + ".1", whole(t1), Hs[i], Ws[i], Slice{-2, 0, 4 * kRegMax}, Slice(), i, nullptr, (p + ".2").c_str());
@@ -958,6 +973,7 @@ static TensorRef tref(const Plan &P, const Slice &s, int boff = 0) {
     }
     t.p = (char *)b.p + (int64_t)boff * b.per_img() * (b.f32 ? 4 : 2);  // sub-batch `boff` owns its own image range of every buffer
     t.bs = b.per_img(); t.cs = b.C; t.co = s.co;
+    if (b.blk32) { t.cs = b.blk32; t.cpb = b.blk32 / 4; t.ps = (int64_t)b.H * b.W * b.blk32; }  // [image][C / 8][pixel][8]
     return t;
 }
 
@@ -1007,7 +1023,10 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     o.p = head + (int64_t)P.lvl_off[op.head_level] * P.no_pad;
                     o.bs = (int64_t)P.A * P.no_pad; o.cs = P.no_pad; o.co = op.out.co;
                     if (op.one_d) o_hw = op.Ho * op.Wo;
-                } else o = tref(P, op.out, boff);
+                } else {
+                    o = tref(P, op.out, boff);
+                    if (op.one_d && o.cpb) o_hw = op.Ho * op.Wo;  // channel-blocked per image: the flattened pixel row is split back into (image, pixel)
+                }
                 if (L.tail_cout > 0) { L.tail_out = o; L.tail_out_hw = o_hw; }
                 else { L.out = o; L.out_hw = o_hw; }
                 L.res = tref(P, op.res, boff);
@@ -1163,13 +1182,13 @@ __global__ void k_half_slice_to_f32(const bf16_t *__restrict__ src, int64_t bs, 
     dst[i] = HX<F16>::one(blk > 0 ? src[(int64_t)(c / blk) * ps + b * bs + pix * blk + c % blk] : src[b * bs + pix * cs + c]);
 }
 
-__global__ void k_f32_slice_copy(const float *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B, float *__restrict__ dst) {
+__global__ void k_f32_slice_copy(const float *__restrict__ src, int64_t bs, int cs, int co, int C, int64_t npix_per_img, int B, float *__restrict__ dst, int blk) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)B * npix_per_img * C) return;
     int c = (int)(i % C) + co;
     int64_t pix = (i / C) % npix_per_img;
     int64_t b = i / ((int64_t)C * npix_per_img);
-    dst[i] = src[b * bs + pix * cs + c];
+    dst[i] = blk > 0 ? src[b * bs + (int64_t)(c / blk) * npix_per_img * blk + pix * blk + c % blk] : src[b * bs + pix * cs + c];
 }
 
 }  // namespace obb
@@ -1231,7 +1250,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"blk32", &ctx->opt.blk32}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
@@ -1408,7 +1427,7 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
     const int64_t d_bs = b.blk > 0 ? hw * b.blk : b.per_img(), d_ps = b.blk > 0 ? (int64_t)P->cap * hw * b.blk : 0;
     if (b.f32)
         hipLaunchKernelGGL(k_f32_slice_copy, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const float *)b.p, (int64_t)b.per_img(), b.C, sl.co, sl.C, hw,
-                           B, out);
+                           B, out, b.blk32);
     else if (ctx->model->f16)
         hipLaunchKernelGGL(k_half_slice_to_f32<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)b.p, d_bs, b.C,
                            sl.co, sl.C, hw, B, out, b.blk, d_ps);

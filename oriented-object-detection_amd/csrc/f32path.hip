@@ -47,6 +47,13 @@ struct C32Params {
     int NI, B;  // NI > 1: a tile = NI whole images of a small map (TH x TW = the map), B images in all
     float inv_twin, inv_tw;
     unsigned in_span_bytes;  // buffer-descriptor range of one image's input slice (its check returns zeros past the end)
+    // channel-blocked tensors (TensorRef::cpb = 2: blocks of 8 channels, per image [C / 8][pixel][8], so that an 8- or 16-channel stage of a
+    // 3x3 layer reads whole dense runs instead of 32- / 64-byte pieces of wide pixel rows -- measured x3.75 HBM re-read on model.3 with plain
+    // NHWC): element (b, pixel, c) = b * bs + (c >> 3) * ps + pixel * 8 + (c & 7); cs = 8.  in: 2-D launches (3x3 / depthwise prologue);
+    // in2: the skip source of a virtual concat; out: the layer's own output (not the TAIL's)
+    int in_blk, in2_blk, out_blk, in_ps, in2_ps, out_ps, up_stages;
+    int64_t in2_bs;
+    unsigned in_sadd, in2_sadd;  // bytes from one channel stage to the next
 };
 
 // SiLU with the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): relative error <= ~1e-6 for |x| <= 10, below the
@@ -75,7 +82,9 @@ __device__ __forceinline__ float silu32(float x) { return x * __builtin_amdgcn_r
 //     timing-only build cost 20-27 % on every MFMA-bound layer) -- and with the cout order below a lane's eight couts are 32 contiguous
 //     bytes, the four lanes of a pixel a whole 128-byte line.  Fragment nc, accumulator row g * 4 + j <-> cout 32 * block + g * 8 + nc * 4 + j
 //     (pack_conv32_weights permutes the rows accordingly).
-template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1>
+//   * BLK: some operand lives in 8-channel blocks (C32Params::in_blk / in2_blk / out_blk); a template switch, so that the plain forms carry
+//     none of its address arithmetic or parameters (with run-time flags only, every 1x1 form lost 5-10 % to the extra scalar registers)
+template <int KS, int MFM, int WC, int NW, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1, bool BLK = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P) {  // <= 128 VGPRs: two workgroups per CU
     static_assert(NC == 1 || (NC == 2 && TAIL == 0 && !DW && !IN_U8), "two cout fragments per wave: plain / VCAT forms only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,14 +183,19 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                 const int iy = (int)(((float)pq + 0.5f) * P.inv_twin), ix = pq - iy * TWin;
                 const int gy = iy0 + iy, gx = ix0 + ix;
                 const bool ok = idx < nchunk && il < T.nimg && gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+                const int cch = c * 4;  // first channel of this chunk inside its stage
                 if constexpr (VCAT) {  // 1-D: gx = flattened (image, y, x) of the full-resolution level
                     const int bb = gx / P.up_HW, r = gx - bb * P.up_HW;
                     const int yy = r / P.up_W, xx = r - yy * P.up_W;
                     const int64_t sp = (int64_t)bb * (P.up_HW >> 2) + (int64_t)(yy >> 1) * (P.up_W >> 1) + (xx >> 1);
-                    goff[k] = ok ? (unsigned)((sp * P.in_cs + c * 4) * 4) : NOPIX;
-                    goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + c * 4) * 4) : NOPIX;
+                    goff[k] = ok ? (unsigned)((sp * P.in_cs + cch) * 4) : NOPIX;
+                    if constexpr (BLK) {
+                        const int c2 = P.in2_blk ? (cch >> 3) * P.in2_ps + (cch & 7) : cch;
+                        goff2[k] = ok ? (unsigned)(((int64_t)bb * P.in2_bs + (int64_t)r * P.in2_cs + c2) * 4) : NOPIX;
+                    } else goff2[k] = ok ? (unsigned)(((int64_t)gx * P.in2_cs + cch) * 4) : NOPIX;
                 } else {
-                    goff[k] = ok ? (unsigned)(((int64_t)il * P.in_bs + ((int64_t)gy * P.Win + gx) * P.in_cs + c * 4) * 4) : NOPIX;
+                    const int c1 = (BLK && P.in_blk) ? (cch >> 3) * P.in_ps + (cch & 7) : cch;
+                    goff[k] = ok ? (unsigned)(((int64_t)il * P.in_bs + ((int64_t)gy * P.Win + gx) * P.in_cs + c1) * 4) : NOPIX;
                 }
             }
         }
@@ -203,10 +217,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         }
         if constexpr (!IN_U8) {
             bool second = false;
-            unsigned add = (unsigned)(stage * P.CK * 4);
+            unsigned add = BLK ? (unsigned)stage * P.in_sadd : (unsigned)(stage * P.CK * 4);
             if constexpr (VCAT) {
                 second = stage * P.CK >= P.up_c;
-                if (second) add -= (unsigned)(P.up_c * 4);
+                if (second) add = BLK ? (unsigned)(stage - P.up_stages) * P.in2_sadd : add - (unsigned)(P.up_c * 4);
             }
 #pragma unroll
             for (int k = 0; k < MAXLD; ++k) {
@@ -287,23 +301,39 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         const bool last = stage + 1 == P.nstage;
         if constexpr (DW) {  // depthwise 3x3 + bias + SiLU of this stage's channels: input tile (LDS) -> B-operand tile (LDS)
             const float *dwl = reinterpret_cast<const float *>(wlds + WC * P.wcb);  // [9 taps + bias][CK]
-            for (int idx = tid; idx < npix * cpk; idx += NT) {
-                const int p = idx >> P.sh, c = idx & (cpk - 1);
-                const int ty = (int)(((float)p + 0.5f) * P.inv_tw), tx = p - ty * P.TW;
+            // an item = TWO horizontally adjacent output pixels x one 4-channel chunk: per tap row 4 input vectors + 3 weight vectors feed 6
+            // fma groups (12 + 9 LDS reads per pixel pair where one pixel per item took 18 + 18: the depthwise phase was LDS-bandwidth-bound,
+            // about as long as the stage's MFMAs); the sums run in the same (ky, kx) order per output, so the results are unchanged
+            const int pairs = (P.TW + 1) >> 1;
+            const float inv_pairs = 1.0f / (float)pairs;
+            for (int idx = tid; idx < P.TH * pairs * cpk; idx += NT) {
+                const int c = idx & (cpk - 1), q = idx >> P.sh;
+                const int ty = (int)(((float)q + 0.5f) * inv_pairs), tx = (q - ty * pairs) * 2;
+                const bool two = tx + 1 < P.TW;  // (odd widths: the last item of a row holds one pixel)
                 const char *src = smem + (ty * TWin + tx) * PST + c * 16;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-                for (int ky = 0; ky < 3; ++ky)  // (a row of taps at a time: the fully unrolled form held 18 operand vectors and spilled)
+                for (int ky = 0; ky < 3; ++ky) {  // (a row of taps at a time: the fully unrolled form held 18 operand vectors and spilled)
+                    const char *row = src + ky * TWin * PST;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(row), v1 = *reinterpret_cast<const float4 *>(row + PST),
+                                 v2 = *reinterpret_cast<const float4 *>(row + 2 * PST), v3 = *reinterpret_cast<const float4 *>(row + (two ? 3 : 2) * PST);
+                    const float4 vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 v = *reinterpret_cast<const float4 *>(src + (ky * TWin + kx) * PST);
+                    for (int kx = 0; kx < 3; ++kx) {  // (per output the taps still run kx = 0, 1, 2 inside ky = 0, 1, 2)
                         const float4 wv = *reinterpret_cast<const float4 *>(dwl + (ky * 3 + kx) * P.CK + c * 4);
-                        a0 = fmaf(v.x, wv.x, a0); a1 = fmaf(v.y, wv.y, a1); a2 = fmaf(v.z, wv.z, a2); a3 = fmaf(v.w, wv.w, a3);
+                        a0[0] = fmaf(vv[kx].x, wv.x, a0[0]); a0[1] = fmaf(vv[kx].y, wv.y, a0[1]); a0[2] = fmaf(vv[kx].z, wv.z, a0[2]); a0[3] = fmaf(vv[kx].w, wv.w, a0[3]);
+                        a1[0] = fmaf(vv[kx + 1].x, wv.x, a1[0]); a1[1] = fmaf(vv[kx + 1].y, wv.y, a1[1]); a1[2] = fmaf(vv[kx + 1].z, wv.z, a1[2]); a1[3] = fmaf(vv[kx + 1].w, wv.w, a1[3]);
                     }
+                }
                 const float4 bvd = *reinterpret_cast<const float4 *>(dwl + 9 * P.CK + c * 4);
-                float4 o = make_float4(a0 + bvd.x, a1 + bvd.y, a2 + bvd.z, a3 + bvd.w);
-                if (P.dw_act) { o.x = silu32(o.x); o.y = silu32(o.y); o.z = silu32(o.z); o.w = silu32(o.w); }
-                *reinterpret_cast<float4 *>(smem + dwb_off + p * PST + c * 16) = o;
+                float4 o0 = make_float4(a0[0] + bvd.x, a0[1] + bvd.y, a0[2] + bvd.z, a0[3] + bvd.w), o1 = make_float4(a1[0] + bvd.x, a1[1] + bvd.y, a1[2] + bvd.z, a1[3] + bvd.w);
+                if (P.dw_act) {
+                    o0.x = silu32(o0.x); o0.y = silu32(o0.y); o0.z = silu32(o0.z); o0.w = silu32(o0.w);
+                    o1.x = silu32(o1.x); o1.y = silu32(o1.y); o1.z = silu32(o1.z); o1.w = silu32(o1.w);
+                }
+                char *dst = smem + dwb_off + (ty * P.TW + tx) * PST + c * 16;
+                *reinterpret_cast<float4 *>(dst) = o0;
+                if (two) *reinterpret_cast<float4 *>(dst + PST) = o1;
             }
             __syncthreads();
         }
@@ -484,7 +514,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
         const int64_t opix = (int64_t)oy * P.Wout + ox;
         int64_t ob = cur.b + il, opx = opix;
         if (P.out_hw > 0) { ob = opx / P.out_hw; opx -= ob * P.out_hw; }
-        float *const op0 = P.out + ob * P.out_bs + opx * P.out_cs + P.out_co + cbase;
+        const int ca = P.out_co + cbase;
+        float *const op0 = P.out + ob * P.out_bs + opx * P.out_cs + ((BLK && P.out_blk) ? (int64_t)(ca >> 3) * P.out_ps + (ca & 7) : (int64_t)ca);
         const float *const rp0 = P.res ? P.res + (int64_t)(cur.b + il) * P.res_bs + opix * P.res_cs + P.res_co + cbase : nullptr;
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) {  // (NC = 2: the two stores of a lane are 32 contiguous bytes)
@@ -697,9 +728,9 @@ size_t conv32_lds_bytes(const Conv32Launch &L) {
     return lds;
 }
 
-template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1>
+template <int KS, int MFM, int WC, bool IN_U8, bool VCAT, int TAIL, bool DW = false, int NC = 1, bool BLK = false>
 static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStream_t st) {
-    const void *fn = (const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC>;
+    const void *fn = (const void *)k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC, BLK>;
     static bool attr_set = false;  // (per instantiation) up to 80 KiB of dynamic LDS: two workgroups per CU
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -738,76 +769,86 @@ static hipError_t launch32_k(const C32Params &P0, dim3 grid, size_t lds, hipStre
             grid = dim3((unsigned)(slots * 8 * P.ncb));
         }
     }
-    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC>), grid, dim3(kNW * 64), lds, st, P);
+    hipLaunchKernelGGL((k_conv_f32<KS, MFM, WC, kNW, IN_U8, VCAT, TAIL, DW, NC, BLK>), grid, dim3(kNW * 64), lds, st, P);
     return hipGetLastError();
 }
 
 // the instantiated (KS, MFM, WC) x feature combinations; anything else is refused (the plan builder only asks for these)
-template <int KS, int MFM, int WC>
+template <int KS, int MFM, int WC, bool BLK>
 static hipError_t launch32_f(const Conv32Launch &L, const C32Params &P, int tail_wc2, dim3 grid, size_t lds, hipStream_t st) {
     if (L.in_u8) {
-        if constexpr (KS == 3 && WC == 1) { if (!tail_wc2 && !L.up_c) return launch32_k<KS, MFM, WC, true, false, 0>(P, grid, lds, st); }
+        if constexpr (KS == 3 && WC == 1 && !BLK) { if (!tail_wc2 && !L.up_c) return launch32_k<KS, MFM, WC, true, false, 0>(P, grid, lds, st); }
         return hipErrorInvalidValue;
     }
     if (L.up_c > 0) {
-        if constexpr (KS == 1 && WC == 4) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0>(P, grid, lds, st); }
+        if constexpr (KS == 1 && WC == 4 && !BLK) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0>(P, grid, lds, st); }
         return hipErrorInvalidValue;
     }
     if (L.dw) {
         if constexpr (KS == 1 && WC == 4) {
-            if (tail_wc2 == 0) return launch32_k<KS, MFM, WC, false, false, 0, true>(P, grid, lds, st);
-            if (tail_wc2 == 1) return launch32_k<KS, MFM, WC, false, false, 1, true>(P, grid, lds, st);
+            if (tail_wc2 == 0) return launch32_k<KS, MFM, WC, false, false, 0, true, 1, BLK>(P, grid, lds, st);
+            if (tail_wc2 == 1) return launch32_k<KS, MFM, WC, false, false, 1, true, 1, BLK>(P, grid, lds, st);
         }
         return hipErrorInvalidValue;
     }
     switch (tail_wc2) {
-        case 0: return launch32_k<KS, MFM, WC, false, false, 0>(P, grid, lds, st);
-        case 1: if constexpr (WC == 1 || WC == 4) return launch32_k<KS, MFM, WC, false, false, 1>(P, grid, lds, st); break;
-        case 2: if constexpr (WC == 2) return launch32_k<KS, MFM, WC, false, false, 2>(P, grid, lds, st); break;
-        case 4: if constexpr (WC == 4) return launch32_k<KS, MFM, WC, false, false, 4>(P, grid, lds, st); break;
+        case 0: return launch32_k<KS, MFM, WC, false, false, 0, false, 1, BLK>(P, grid, lds, st);
+        case 1: if constexpr (WC == 1 || WC == 4) return launch32_k<KS, MFM, WC, false, false, 1, false, 1, BLK>(P, grid, lds, st); break;
+        case 2: if constexpr (WC == 2) return launch32_k<KS, MFM, WC, false, false, 2, false, 1, BLK>(P, grid, lds, st); break;
+        case 4: if constexpr (WC == 4) return launch32_k<KS, MFM, WC, false, false, 4, false, 1, BLK>(P, grid, lds, st); break;
     }
     return hipErrorInvalidValue;
 }
 
-template <int KS>
+template <int KS, bool BLK>
 static hipError_t launch32_wc(const Conv32Launch &L, const C32Params &P, int tail_wc2, dim3 grid, size_t lds, hipStream_t st) {
     if (L.NC == 2) {  // two cout fragments per wave: 2 waves along cout, 3 or 4 pixel fragments per wave; plain and (1x1) VCAT forms
         if (L.WC != 2 || tail_wc2 || L.dw || L.in_u8) return hipErrorInvalidValue;
         if (L.up_c > 0) {
             if constexpr (KS == 1) {
-                if (L.MFM == 4) return launch32_k<KS, 4, 2, false, true, 0, false, 2>(P, grid, lds, st);
-                if (L.MFM == 3) return launch32_k<KS, 3, 2, false, true, 0, false, 2>(P, grid, lds, st);
+                if (L.MFM == 4) return launch32_k<KS, 4, 2, false, true, 0, false, 2, BLK>(P, grid, lds, st);
+                if (L.MFM == 3) return launch32_k<KS, 3, 2, false, true, 0, false, 2, BLK>(P, grid, lds, st);
             }
             return hipErrorInvalidValue;
         }
-        if (L.MFM == 4) return launch32_k<KS, 4, 2, false, false, 0, false, 2>(P, grid, lds, st);
-        if (L.MFM == 3) return launch32_k<KS, 3, 2, false, false, 0, false, 2>(P, grid, lds, st);
+        if (L.MFM == 4) return launch32_k<KS, 4, 2, false, false, 0, false, 2, BLK>(P, grid, lds, st);
+        if (L.MFM == 3) return launch32_k<KS, 3, 2, false, false, 0, false, 2, BLK>(P, grid, lds, st);
         return hipErrorInvalidValue;
     }
     switch (L.WC * 16 + L.MFM) {
-        case 4 * 16 + 7: return launch32_f<KS, 7, 4>(L, P, tail_wc2, grid, lds, st);
-        case 4 * 16 + 6: return launch32_f<KS, 6, 4>(L, P, tail_wc2, grid, lds, st);
-        case 4 * 16 + 5: return launch32_f<KS, 5, 4>(L, P, tail_wc2, grid, lds, st);
-        case 4 * 16 + 4: return launch32_f<KS, 4, 4>(L, P, tail_wc2, grid, lds, st);
-        case 2 * 16 + 4: return launch32_f<KS, 4, 2>(L, P, tail_wc2, grid, lds, st);
-        case 2 * 16 + 3: return launch32_f<KS, 3, 2>(L, P, tail_wc2, grid, lds, st);
-        case 2 * 16 + 2: return launch32_f<KS, 2, 2>(L, P, tail_wc2, grid, lds, st);
-        case 1 * 16 + 4: return launch32_f<KS, 4, 1>(L, P, tail_wc2, grid, lds, st);
-        case 1 * 16 + 3: return launch32_f<KS, 3, 1>(L, P, tail_wc2, grid, lds, st);
-        case 1 * 16 + 2: return launch32_f<KS, 2, 1>(L, P, tail_wc2, grid, lds, st);
-        case 1 * 16 + 1: return launch32_f<KS, 1, 1>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 7: return launch32_f<KS, 7, 4, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 6: return launch32_f<KS, 6, 4, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 5: return launch32_f<KS, 5, 4, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 4 * 16 + 4: return launch32_f<KS, 4, 4, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 4: return launch32_f<KS, 4, 2, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 3: return launch32_f<KS, 3, 2, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 2 * 16 + 2: return launch32_f<KS, 2, 2, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 4: return launch32_f<KS, 4, 1, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 3: return launch32_f<KS, 3, 1, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 2: return launch32_f<KS, 2, 1, BLK>(L, P, tail_wc2, grid, lds, st);
+        case 1 * 16 + 1: return launch32_f<KS, 1, 1, BLK>(L, P, tail_wc2, grid, lds, st);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
-    if (L.in.cpb || L.out.cpb || L.res.cpb || L.in2.cpb || L.tail_out.cpb) return hipErrorInvalidValue;  // plain NHWC only
+    if (L.res.cpb || L.tail_out.cpb) return hipErrorInvalidValue;  // plain NHWC only
+    {   // channel-blocked (by 8) tensors: see C32Params
+        auto blk8 = [](const TensorRef &t) { return t.cpb == 2 && t.cs == 8 && t.co % 8 == 0 && t.ps > 0 && t.ps < (1ll << 28); };
+        if (L.in.cpb && (!blk8(L.in) || L.in_u8 || L.up_c > 0 || (L.ks != 3 && !L.dw) || L.CK % 8 || L.cin % 8)) return hipErrorInvalidValue;
+        if (L.in2.cpb && (!blk8(L.in2) || L.up_c <= 0 || L.CK % 8)) return hipErrorInvalidValue;
+        // (1x1 layers are issued over the flattened batch: their blocked output needs the per-image split of out_hw)
+        if (L.out.cpb && (!blk8(L.out) || L.tail_cout > 0 || L.cout % 8 || (L.ks == 1 && !L.dw && L.out_hw <= 0))) return hipErrorInvalidValue;
+    }
     if ((L.ks != 1 && L.ks != 3) || (L.WC != 1 && L.WC != 2 && L.WC != 4) || (L.NC != 1 && L.NC != 2)) return hipErrorInvalidValue;
     if (L.NC == 2 && (L.cout % 32 || L.tail_cout > 0 || L.dw || L.in_u8 || L.NI > 1)) return hipErrorInvalidValue;
     C32Params P;
     memset(&P, 0, sizeof P);
     P.in = L.in.p; P.in_bs = L.in.bs; P.in_cs = L.in.cs; P.in_co = L.in.co;
     P.out = (float *)L.out.p; P.out_bs = L.out.bs; P.out_cs = L.out.cs; P.out_co = L.out.co;
+    if (L.in.cpb) { P.in_blk = 1; P.in_ps = (int)L.in.ps; P.in = (const float *)L.in.p + (int64_t)(L.in.co >> 3) * L.in.ps; P.in_co = 0; }
+    if (L.out.cpb) { P.out_blk = 1; P.out_ps = (int)L.out.ps; }
+    P.in_sadd = L.in.cpb ? (unsigned)((int64_t)(L.CK / 8) * L.in.ps * 4) : (unsigned)(L.CK * 4);
     P.res = (const float *)L.res.p; P.res_bs = L.res.bs; P.res_cs = L.res.cs; P.res_co = L.res.co;
     P.wpk = L.wpk; P.bias = L.bias; P.lut = L.lut;
     P.Hin = L.Hin; P.Win = L.Win; P.Hout = L.Hout; P.Wout = L.Wout; P.cin = L.cin; P.cout = L.cout; P.stride = L.stride; P.act = L.act;
@@ -838,15 +879,24 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     P.inv_tw = 1.0f / (float)L.TW;
     {
         int64_t span = ((int64_t)L.Hin * L.Win * L.in.cs - L.in.co) * 4 + (int64_t)(NI - 1) * L.in.bs * 4;  // from the slice's first element to the end of the (last) image
+        if (L.in.cpb) span = (L.in.bs - (int64_t)(L.in.co >> 3) * L.in.ps) * 4 + (int64_t)(NI - 1) * L.in.bs * 4;
         if (L.up_c > 0) {  // virtual [upsample | skip] concat: 1-D 1x1 launches over plain NHWC sources only
             if (L.ks != 1 || L.in_u8 || L.B != 1 || L.Hin != 1 || !L.in2.p || L.up_c % L.CK || L.up_c >= L.cin || (L.up_W & 1) || (L.up_HW % L.up_W) ||
                 ((L.up_HW / L.up_W) & 1) || L.Win % L.up_HW || (L.in2.cs & 3) || (L.in2.co & 3))
                 return hipErrorInvalidValue;
             span = ((int64_t)(L.Win / 4) * L.in.cs - L.in.co) * 4;  // the low-resolution source
-            const int64_t s2 = ((int64_t)L.Win * L.in2.cs - L.in2.co) * 4;
+            int64_t s2 = ((int64_t)L.Win * L.in2.cs - L.in2.co) * 4;
+            P.in2 = L.in2.p; P.in2_cs = L.in2.cs; P.in2_co = L.in2.co;
+            P.in2_bs = (int64_t)L.up_HW * L.in2.cs; P.in2_sadd = (unsigned)(L.CK * 4);
+            if (L.in2.cpb) {  // the skip tensor in 8-channel blocks per image
+                P.in2_blk = 1; P.in2_ps = (int)L.in2.ps; P.in2_bs = L.in2.bs;
+                P.in2 = (const float *)L.in2.p + (int64_t)(L.in2.co >> 3) * L.in2.ps; P.in2_co = 0;
+                P.in2_sadd = (unsigned)((int64_t)(L.CK / 8) * L.in2.ps * 4);
+                s2 = ((int64_t)(L.Win / L.up_HW) * L.in2.bs - (int64_t)(L.in2.co >> 3) * L.in2.ps) * 4;
+            }
             if (s2 <= 0 || s2 >= (1ll << 32) - 65536) return hipErrorInvalidValue;
-            P.in2 = L.in2.p; P.in2_cs = L.in2.cs; P.in2_co = L.in2.co; P.in2_span_bytes = (unsigned)s2;
-            P.up_c = L.up_c; P.up_W = L.up_W; P.up_HW = L.up_HW;
+            P.in2_span_bytes = (unsigned)s2;
+            P.up_c = L.up_c; P.up_W = L.up_W; P.up_HW = L.up_HW; P.up_stages = L.up_c / L.CK;
         }
         if (!L.in_u8 && (span <= 0 || span >= (1ll << 32) - 65536)) return hipErrorInvalidValue;  // 32-bit buffer offsets
         P.in_span_bytes = L.in_u8 ? 0u : (unsigned)span;
@@ -869,7 +919,8 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
     const size_t lds = conv32_lds_bytes(L);
     if (lds > 80 * 1024 || P.kst > (L.ks == 3 ? 9 : 4)) return hipErrorInvalidValue;  // (kst bound: the weight-fetch plan of the kernel, MAXW)
     dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * P.ncb));
-    return L.ks == 3 ? launch32_wc<3>(L, P, tail_wc2, grid, lds, st) : launch32_wc<1>(L, P, tail_wc2, grid, lds, st);
+    if (L.in.cpb || L.in2.cpb || L.out.cpb) return L.ks == 3 ? launch32_wc<3, true>(L, P, tail_wc2, grid, lds, st) : launch32_wc<1, true>(L, P, tail_wc2, grid, lds, st);
+    return L.ks == 3 ? launch32_wc<3, false>(L, P, tail_wc2, grid, lds, st) : launch32_wc<1, false>(L, P, tail_wc2, grid, lds, st);
 }
 
 // ------------------------------------------------------------------------------------------------ network input layer as row stripes

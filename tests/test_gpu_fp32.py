@@ -121,6 +121,24 @@ def test_fp32_two_fragment_form_is_bit_identical(ood, nets, h, w, B):
     assert torch.equal(one[..., :77], two[..., :77]), float((one - two)[..., :77].abs().max())
 
 
+@pytest.mark.parametrize("h,w,B,ch", [(416, 416, 5, 3), (128, 128, 33, 3), (416, 288, 2, 3), (64, 96, 3, 3), (416, 416, 3, 4)])
+def test_fp32_channel_blocked_buffers_are_bit_identical(ood, nets, h, w, B, ch):
+    """`blk32`: the tensors read by 3x3 convs in 8- / 16-channel stages (x2, x4, x6, x16, x19, the first convs of the box branch) stored as
+    8-channel blocks per image instead of plain NHWC -- a pure change of addresses (the stage then reads dense runs instead of 32-byte pieces
+    of wide pixel rows): heads BIT FOR BIT, and the named activations read back through the blocked layout equal the plain ones."""
+    ops = ood.ops
+    net = nets[416] if ch == 3 else Yolo11OBB("n", nc=12, ch=4, seed=3)
+    x = torch.as_tensor(_tiles(23 + h + B, B, h, w, ch)).cuda()
+    ops.model_load(net.to_blob(), precision="f32", blk32=False)
+    plain = ops.forward(x).cpu()
+    taps = {n: ops.debug_activation(n, B, h, w).cpu() for n in ("x2", "x4", "x16", "x19")}
+    ops.model_load(net.to_blob(), precision="f32")
+    blocked = ops.forward(x).cpu()
+    assert torch.equal(plain[..., :77], blocked[..., :77]), float((plain - blocked)[..., :77].abs().max())
+    for n, t in taps.items():
+        assert torch.equal(t, ops.debug_activation(n, B, h, w).cpu()), n
+
+
 def test_rounds_are_sized_by_pixels_and_do_not_change_results(ood, nets):
     """A round of the forward holds 1024 tiles of 416 x 416 or proportionally more smaller ones (at most 8192): 8200 tiles of 64 x 64 are two
     rounds (8192 + 8); every tile's head must equal what the same tile gives in a small batch of its own."""

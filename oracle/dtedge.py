@@ -14,8 +14,14 @@ from its documented algorithm; **parity with cv2 itself is unpinned** (no fixtur
     cv2.distanceTransform(DIST_L2, 3) two-pass 3x3 chamfer in 16.16 fixed point (a = 0.955, b = 1.3693), result * 2^-16 as float32
     cv2.normalize(NORM_MINMAX, 0..1)  float32: x * scale + shift with scale = 1 / (max - min), shift = -min * scale
 
-Everything numpy (np.percentile with float64 linear interpolation, float64 promotion of the arithmetic that follows it, truncating
-astype(uint8)) is executed by numpy itself, exactly as in the reference."""
+numpy steps: np.percentile (float64 linear interpolation) is executed by numpy itself.  The arithmetic BEHIND the percentiles follows the
+promotion rules of the reference's pinned numpy==1.26.4 (requirements.txt:1), not those of the numpy that runs this file: before NEP 50
+(numpy < 2) a float32 ARRAY combined with a numpy float64 SCALAR stays float32 (value-based casting), so `acc >= hi`, `dist - lo`,
+`/ max(1e-6, hi - lo)`, `np.exp(-dist / tau)`, the 0.7 / 0.3 blend and `soft * 255` all run in float32 there; numpy >= 2 would promote every
+one of them to float64.  The casts are therefore explicit below.  np.exp on float32 is numpy's SIMD routine (a few ulp, build-dependent):
+restated as float32(exp64(x)) with exp64 a fixed double-precision polynomial of IEEE basic operations -- within 0.5000001 ulp of the true
+value, and bit-reproducible on the device (csrc/dtedge.hip evaluates the same operations); parity with numpy's own float32 exp is
+unpinned (it may differ by one ulp, i.e. one grey level on ~1e-5 of the pixels)."""
 import numpy as np
 
 MS_SIGMAS = (0, 0.6, 1.2, 2.4)   # Detect_OBB.py:29
@@ -110,6 +116,21 @@ def normalize_minmax01(acc):
     return (acc * np.float32(scale) + np.float32(shift)).astype(np.float32)
 
 
+_EXP_C = [1.0 / float(__import__("math").factorial(k)) for k in range(15)]  # 1 / k!: correctly rounded quotients of exact integers
+
+
+def exp32(x):
+    """float32(exp(x)) for float32 x in [-0.5, 0]: Horner evaluation of the degree-14 Taylor polynomial in float64 (remainder < 1e-18),
+    one multiplication and one addition per step, each rounded -- the device runs the identical sequence (no fused multiply-add)"""
+    x = np.asarray(x, np.float32).astype(np.float64)
+    assert x.size == 0 or (float(x.min()) >= -0.5 and float(x.max()) <= 0.0)
+    p = np.full_like(x, _EXP_C[14])
+    for k in range(13, -1, -1):
+        p = p * x
+        p = p + _EXP_C[k]
+    return p.astype(np.float32)
+
+
 def build_multich(bgr, out_channels=4):
     """Detect_OBB.py:87-133"""
     assert out_channels in (3, 4)
@@ -123,18 +144,20 @@ def build_multich(bgr, out_channels=4):
         mag = scharr_mag(blur)
         acc = mag if acc is None else np.maximum(acc, mag)
     lo, hi = np.percentile(acc, [DT_P_LO, DT_P_HI])
-    edges = (acc >= hi).astype(np.uint8) * 255
+    edges = (acc >= np.float32(hi)).astype(np.uint8) * 255  # numpy 1.26: the float64 scalar is cast to the array's float32 before the compare
     if DT_MORPH_OPEN > 0:
         for _ in range(DT_MORPH_OPEN):
             edges = morph_open_cross(edges)
     non_edge = np.where(edges > 0, 0, 255).astype(np.uint8)
     dist = distance_transform_3x3(non_edge).astype(np.float32)
     lo, hi = np.percentile(dist, [1, 99])
-    dist = np.clip((dist - lo) / max(1e-6, (hi - lo)), 0, 1)
-    tau = 3.0
-    soft = np.exp(-dist / tau)
+    den = max(1e-6, (hi - lo))                                          # float64 scalars so far
+    dist = np.clip((dist - np.float32(lo)) / np.float32(den), np.float32(0), np.float32(1))  # float32 from here on (numpy 1.26 value-based casting)
+    tau = np.float32(3.0)
+    soft = exp32(-dist / tau)
     acc8_nrm = normalize_minmax01(acc)
-    soft = 0.7 * soft + 0.3 * acc8_nrm
-    soft = np.clip(soft, 0, 1)
-    dt_edge = (soft * 255).astype(np.uint8)
+    soft = np.float32(0.7) * soft + np.float32(0.3) * acc8_nrm
+    soft = np.clip(soft, np.float32(0), np.float32(1))
+    assert soft.dtype == np.float32
+    dt_edge = (soft * np.float32(255)).astype(np.uint8)
     return np.ascontiguousarray(np.dstack([rgb_raw, dt_edge]).astype(np.uint8))

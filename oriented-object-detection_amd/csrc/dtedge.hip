@@ -441,7 +441,8 @@ __global__ __launch_bounds__(kSelThreads) void k_dt_select(const float *__restri
 
 // ---------------------------------------------------------------------------------------------------------------- k_dt_edges
 
-// edges = acc >= thr (numpy: float64 threshold, float32 values promoted), then opening with the 3x3 cross; pixels outside the image
+// edges = acc >= thr (the reference's numpy 1.26.4: the float64 percentile is a SCALAR, cast to the array's float32 before the compare --
+// value-based casting, changed by NEP 50 in numpy 2), then opening with the 3x3 cross; pixels outside the image
 // do not take part (erosion sees 255 there, dilation 0).  Output: 255 / 0 per pixel, pitch P.
 __global__ __launch_bounds__(256) void k_dt_edges(const float *__restrict__ acc, size_t crop_stride, int h, int w, int pitch, const DtStats *__restrict__ stats,
                                                   uint8_t *__restrict__ edges, size_t edge_stride) {
@@ -450,11 +451,11 @@ __global__ __launch_bounds__(256) void k_dt_edges(const float *__restrict__ acc,
     __shared__ uint8_t s_r[RH * RW];
     const int tid = threadIdx.x, x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const float *a = acc + (size_t)blockIdx.z * crop_stride;
-    const double thr = stats[blockIdx.z].thr;
+    const float thr = (float)stats[blockIdx.z].thr;
     for (int i = tid; i < EH * EW; i += 256) {
         const int r = i / EW, c = i - r * EW, y = y0 - 2 + r, x = x0 - 2 + c;
         uint8_t e = 255;
-        if (y >= 0 && y < h && x >= 0 && x < w) e = ((double)a[(size_t)y * pitch + x] >= thr) ? 255 : 0;
+        if (y >= 0 && y < h && x >= 0 && x < w) e = (a[(size_t)y * pitch + x] >= thr) ? 255 : 0;
         s_e[i] = e;
     }
     __syncthreads();
@@ -637,7 +638,25 @@ __global__ __launch_bounds__(64) void k_dt_chamfer(const uint8_t *__restrict__ e
 
 // ---------------------------------------------------------------------------------------------------------------- k_dt_blend
 
-// 0.7 exp(-clip((d - lo) / max(1e-6, hi - lo)) / 3) + 0.3 minmax(acc), clipped, * 255, truncated; output RGB + that channel
+// 0.7 exp(-clip((d - lo) / max(1e-6, hi - lo)) / 3) + 0.3 minmax(acc), clipped, * 255, truncated; output RGB + that channel.
+// Arithmetic as the reference's pinned numpy 1.26.4 runs it (Detect_OBB.py:126-133): lo / hi are float64 SCALARS, and a float32 array
+// combined with a float64 scalar stays float32 there (value-based casting; numpy >= 2 would promote), so every step below is one
+// correctly rounded float32 operation (no contraction: the build uses -ffp-contract=off).  exp: float32(exp64(x)) with exp64 the degree-14
+// Taylor polynomial in Horner form, double multiply + add per step -- the same IEEE operations as oracle/dtedge.py::exp32, hence the
+// same bytes; numpy's own float32 SIMD exp may differ from it by an ulp (unpinned).
+__device__ __forceinline__ float dt_exp32(float xf) {  // xf in [-0.5, 0]
+    constexpr double C[15] = {1.0, 1.0, 1.0 / 2.0, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0,
+                              1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, 1.0 / 87178291200.0};
+    const double x = (double)xf;
+    double p = C[14];
+#pragma unroll
+    for (int k = 13; k >= 0; --k) {
+        p = p * x;
+        p = p + C[k];
+    }
+    return (float)p;
+}
+
 __global__ __launch_bounds__(256) void k_dt_blend(const uint8_t *__restrict__ bgr, const float *__restrict__ acc, size_t acc_stride, const float *__restrict__ dist,
                                                   size_t dist_stride, const DtStats *__restrict__ stats, int h, int w, int pitch, uint8_t *__restrict__ out4) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -647,14 +666,15 @@ __global__ __launch_bounds__(256) void k_dt_blend(const uint8_t *__restrict__ bg
     const uint8_t *src = bgr + blockIdx.z * n * 3;
     const double scale_d = (st.mx > st.mn) ? 1.0 / ((double)st.mx - (double)st.mn) : 0.0;
     const float scale = (float)scale_d, shift = (float)(-(double)st.mn * scale_d);
-    const double den = fmax(1e-6, st.hi - st.lo);
-    double d = ((double)dist[blockIdx.z * dist_stride + ip] - st.lo) / den;
-    d = fmin(fmax(d, 0.0), 1.0);
-    double soft = exp(-d / 3.0);
+    const float lo = (float)st.lo, den = (float)fmax(1e-6, st.hi - st.lo);  // (hi - lo and the max in float64: both scalars)
+    float d = (dist[blockIdx.z * dist_stride + ip] - lo) / den;
+    d = fminf(fmaxf(d, 0.0f), 1.0f);
+    float soft = dt_exp32(-d / 3.0f);
     const float nrm = acc[blockIdx.z * acc_stride + ip] * scale + shift;
-    soft = 0.7 * soft + (double)(0.3f * nrm);  // numpy: python scalar * float32 array stays float32, then promotes in the sum
-    soft = fmin(fmax(soft, 0.0), 1.0);
-    const unsigned o = (unsigned)src[i * 3 + 2] | ((unsigned)src[i * 3 + 1] << 8) | ((unsigned)src[i * 3] << 16) | ((unsigned)(uint8_t)(soft * 255.0) << 24);
+    const float a7 = 0.7f * soft, a3 = 0.3f * nrm;
+    soft = a7 + a3;
+    soft = fminf(fmaxf(soft, 0.0f), 1.0f);
+    const unsigned o = (unsigned)src[i * 3 + 2] | ((unsigned)src[i * 3 + 1] << 8) | ((unsigned)src[i * 3] << 16) | ((unsigned)(uint8_t)(soft * 255.0f) << 24);
     reinterpret_cast<unsigned *>(out4)[blockIdx.z * n + i] = o;
 }
 

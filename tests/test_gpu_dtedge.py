@@ -1,6 +1,6 @@
 """Row f3: the 4-channel input builder (RGB + distance-transform edge channel, Detect_OBB.py:87-133) on the device vs the numpy
-restatement in oracle/dtedge.py.  Integer stages are bit-exact by construction; the last step evaluates exp() in float64 on both
-sides, whose last-bit differences can move a truncated uint8 by one on isolated pixels."""
+restatement in oracle/dtedge.py: byte for byte.  Integer stages are exact by construction; the float tail follows the float32 promotion of
+the reference's pinned numpy 1.26.4, with exp() as the same sequence of IEEE double operations on both sides (see oracle/dtedge.py)."""
 import numpy as np
 import pytest
 import torch
@@ -48,11 +48,9 @@ def test_build_multich_matches_numpy_restatement(idx):
     assert np.array_equal(got[0, ..., :3], img[..., ::-1])               # RGB
     d = np.abs(got[0, ..., 3].astype(np.int32) - exp[..., 3].astype(np.int32))
     print(img.shape, "dt channel: max diff", d.max(), "pixels differing", int((d > 0).sum()), "of", d.size, "range", exp[..., 3].min(), exp[..., 3].max())
-    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+    assert np.array_equal(got[0], exp)
     for k, im in ((1, img[::-1].copy()), (2, img[:, ::-1].copy())):
-        e = od.build_multich(im, 4)
-        dd = np.abs(got[k, ..., 3].astype(np.int32) - e[..., 3].astype(np.int32))
-        assert dd.max() <= 1 and (dd > 0).mean() < 5e-3
+        assert np.array_equal(got[k], od.build_multich(im, 4)), k
 
 
 def test_build_multich_ragged_shapes():
@@ -69,8 +67,7 @@ def test_build_multich_ragged_shapes():
         for k in range(2):
             exp = od.build_multich(batch[k], 4)
             d = np.abs(got[k, ..., 3].astype(np.int32) - exp[..., 3].astype(np.int32))
-            assert np.array_equal(got[k, ..., :3], batch[k][..., ::-1])
-            assert d.max() <= 1 and (d > 0).sum() <= max(1, d.size // 200), ((h, w), k, int(d.max()), int((d > 0).sum()))
+            assert np.array_equal(got[k], exp), ((h, w), k, int(d.max()), int((d > 0).sum()))
 
 
 def test_build_multich_rejects_unsupported_sizes():

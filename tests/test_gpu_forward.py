@@ -358,6 +358,7 @@ def test_closing_1x1_behind_the_bottleneck(ops, net_n):
 
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 1), (192, 416, 2)])
 def test_head_matches_oracles(ops, net_n, h, w, B):
+    ops.model_load(net_n.to_blob(), precision=net_n.prec)  # explicitly: the default options, whatever the previous test left loaded
     x = _tiles(10 + h + w, B, h, w)
     head = ops.forward(torch.as_tensor(x).cuda()).cpu()[..., :77]
     ref16 = net_n.forward_raw(x, net_n.prec)
@@ -368,16 +369,18 @@ def test_head_matches_oracles(ops, net_n, h, w, B):
     b32 = (ref16 - ref32).abs()
     print(net_n.prec, h, w, "vs 16-bit oracle max/mean", float(d16.max()), float(d16.mean()), "vs fp32", float(d32.max()), float(d32.mean()),
           "oracle bf16-vs-fp32", float(b32.max()), float(b32.mean()))
-    # same arithmetic model: only fp32 summation order + rare bf16 1-ulp flips propagate
-    tol = 1.0 if net_n.prec == 'bf16' else 0.3
-    assert float(d16.mean()) < 0.06 * tol and float(d16.max()) < 3.0 * tol
+    # same arithmetic model: only fp32 summation order + rare 16-bit 1-ulp flips propagate.  Bounds = the largest value measured over the four
+    # shapes (round 4: f16 max 0.182 / mean 0.0062, bf16 max 1.205 / mean 0.036) + 50 %
+    mx16, mean16 = (1.81, 0.054) if net_n.prec == 'bf16' else (0.28, 0.0093)
+    assert float(d16.mean()) < mean16 and float(d16.max()) < mx16
     # against the reference's fp32 arithmetic the HIP path is as close as the bf16 model itself (stated tolerance)
     assert float(d32.mean()) < 1.5 * float(b32.mean()) + 1e-3
     conf16 = torch.sigmoid(ref32[..., 64:76]).amax(-1)
     confg = torch.sigmoid(head[..., 64:76]).amax(-1)
     dc = (conf16 - confg).abs()
     print('conf |d| max/mean', float(dc.max()), float(dc.mean()))
-    assert float(dc.mean()) < 2e-2 * tol and float(dc.max()) < 0.6 * tol
+    cmx, cmean = (0.61, 0.024) if net_n.prec == 'bf16' else (0.086, 0.0026)  # measured 0.406 / 0.0158 (bf16), 0.057 / 0.0017 (f16), + 50 %
+    assert float(dc.mean()) < cmean and float(dc.max()) < cmx
 
 
 def test_forward_is_deterministic_and_batch_invariant(ops, net_n):

@@ -280,10 +280,9 @@ def test_fp32_process_image_dual_scale_end_to_end(ood, nets):
 
 def test_fp32_four_channel_end_to_end_no_injection(ood):
     """BASELINE configs[3] on one GPU with NO head injection: a 3-channel BGR image, every crop gets its DT-edge channel on the device
-    (build_multich) and goes through the device's own fp32 forward; the oracle runs its own fp32 forward on the same 4-channel crops
-    (the DT-edge builder has its own parity tests, tests/test_gpu_dtedge.py: on this image its channel differs from the numpy
-    restatement by at most 1 grey level at a few pixels, which is enough to flip a near-tie of the NMS -- so the crops, not the heads,
-    are shared here).  Same bounds as the 3-channel comparisons above; the all-oracle run is compared as a detection set."""
+    (build_multich) and goes through the device's own fp32 forward; the oracle builds the channel with the numpy restatement (byte-identical to
+    the device's, tests/test_gpu_dtedge.py) and runs its own fp32 forward: nothing is shared between the two pipelines but the image.
+    Same bounds as the 3-channel comparisons above."""
     net = Yolo11OBB("n", nc=12, ch=4, seed=2)
     model = ood.model.YOLO(net, imgsz=416, precision="f32")
     assert model.ch == 4
@@ -292,13 +291,9 @@ def test_fp32_four_channel_end_to_end_no_injection(ood):
     img[100:130, 50:600] = 15
     img[200:520, 300:330] = (240, 10, 10)
     got = ood.detect.detect_symbols(img, model, 416, 100)  # 4 tiles: one full, three partial (letterboxed after the channel is built)
-    exp = opl.detect_symbols(img, opl.OracleModel(net, 416, "fp32", multich_fn=lambda crop: ood.detect.build_multich(crop, 4)), 416, 100)
+    exp = opl.detect_symbols(img, opl.OracleModel(net, 416, "fp32"), 416, 100)  # channel built by the numpy restatement, forward by torch-CPU
     assert len(exp) > 5
     _same_dets(got, exp, 2e-4, 0.1, "fp32 4-channel detect_symbols 600x740", max_subst=2)
-    exp_all = opl.detect_symbols(img, opl.OracleModel(net, 416, "fp32"), 416, 100)  # channel built by the numpy restatement as well
-    pairs, ug, ue = _match_sets(got, exp_all)
-    print(f"4-channel, oracle-built channel: {len(got)} vs {len(exp_all)} detections, matched {len(pairs)}, unmatched {ug}/{ue}")
-    assert 2.0 * len(pairs) / (len(got) + len(exp_all)) >= 0.95
 
 
 def test_fp32_process_image_on_the_real_sample_file_no_injection(ood, nets, tmp_path):

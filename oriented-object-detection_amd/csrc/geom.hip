@@ -705,13 +705,21 @@ static constexpr int kSegWords = kSegMax / 64;
 // The cheap class + envelope tests emit a compact candidate-pair list; the expensive fp64 clipping is then spread evenly
 // over all lanes (a row-per-thread loop would leave most of the group idle behind the few crowded rows).
 static constexpr int kSegPairCap = 12288;
+static constexpr int kSegMid = 256, kSegMidPairCap = 4096;
 
 // Segment `seg` = rows [seg_lo[seg], seg_hi[seg]) (a prefix-offset array passes (off, off + 1); the fused per-tile path passes fixed-stride
 // slots with their fill counts).
-__global__ __launch_bounds__(1024) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+// SEGMAX / NT / PAIRCAP: the 512-row form (1024 threads, ~104 KB of LDS: one segment per CU) and a 256-row form (256 threads, 36 KB) for
+// the single-segment call.  (Measured, round 4: giving the 65 .. 256-row segments of a batch the small form does NOT help -- the kernel's time
+// is the latency of its slowest segment, i.e. the exact fp64 clips of a saturated tile's same-class pairs spread over the workgroup's
+// threads: 256 threads took 372 us for what 1024 do in < 483 us, and the two launches add up.)  `skip_above` > 0: longer segments are
+// left to another launch
+template <int SEGMAX, int NT, int PAIRCAP>
+__global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
                                                         const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
                                                         double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
-                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto) {
+                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto, int skip_above) {
+    constexpr int kSegMax = SEGMAX, kSegWords = SEGMAX / 64, kSegPairCap = PAIRCAP;
     __shared__ double skey[kSegMax];
     __shared__ int32_t sord[kSegMax];
     __shared__ int32_t scl[kSegMax];
@@ -719,11 +727,11 @@ __global__ __launch_bounds__(1024) void k_merge_segments(const double *__restric
     __shared__ unsigned long long sbits[kSegMax * kSegWords];
     __shared__ unsigned int spairs[kSegPairCap];
     __shared__ unsigned int npairs_s;
-    const int NT = 1024;
     int seg = blockIdx.x;
     int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     int n = s1 - s0;
     if (n <= skip_upto) { if (n <= 0 && skip_upto == 0 && threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }  // (short ones: k_merge_segments_wave)
+    if (skip_above > 0 && n > skip_above) return;
     if (n > kSegMax) {  // too long for LDS: flag it and write a DEFINED result (identity order, nothing kept); outside a stream capture the
         // host then reruns such segments through the dense path, inside one (no host read possible) the caller sees them dropped, not garbage
         if (threadIdx.x == 0) atomicExch(status, 1);
@@ -1472,8 +1480,8 @@ int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, co
     OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr, order, keep, (int32_t *)nullptr);
     if (n > kSegWave)  // (some segment may be longer than a wave takes)
-        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr,
-                           order, keep, (int32_t *)nullptr, status, kSegWave);
+        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr,
+                           order, keep, (int32_t *)nullptr, status, kSegWave, 0);
     OBB_LAUNCH_CHECK(ctx);
     if (n <= kSegMax) return OBB_OK;  // no segment can be longer than the LDS-resident kernel takes
     // Segments above kSegMax rows were flagged and left untouched by the kernel (a tile with more than 512 detections: max_det > 512, or
@@ -1514,7 +1522,10 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
         if (!segoff || !status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
         hipLaunchKernelGGL(k_set_segment, dim3(1), dim3(64), 0, st, segoff, (int32_t)n, status);  // (a kernel, not a host copy: capturable, no host memory referenced at replay)
-        hipLaunchKernelGGL(k_merge_segments, dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0);
+        if (n <= kSegMid)
+            hipLaunchKernelGGL((k_merge_segments<kSegMid, 256, kSegMidPairCap>), dim3(1), dim3(256), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0);
+        else
+            hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }
@@ -1673,7 +1684,7 @@ int obb_tile_survivors(obb_ctx *ctx, const float *det, const int32_t *count, int
     hipLaunchKernelGGL(k_tile_stage, dim3((unsigned)B), dim3(256), 0, st, det, count, (int)max_det, lb, tile_ids, rects, (int)margin, (int)strike_cls, S);
     hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)B), dim3(64), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep);
     if (max_det > kSegWave)  // (tiles with more than 64 survivors: the workgroup-per-segment form; shorter segments return at once)
-        hipLaunchKernelGGL(k_merge_segments, dim3((unsigned)B), dim3(1024), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep, status, kSegWave);
+        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)B), dim3(1024), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep, status, kSegWave, 0);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nkeep, (int)B, tile_off, n_records);
     hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)B), dim3(64), 0, st, S, order, keep, tile_off, tile_ids, records);
     OBB_LAUNCH_CHECK(ctx);

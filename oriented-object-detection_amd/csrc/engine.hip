@@ -14,6 +14,7 @@
 #include <tuple>
 
 #include "bneck.h"
+#include "c3k2f32.h"
 #include "c3kimg.h"
 #include "ctx.h"
 #include "dwpw.h"
@@ -47,7 +48,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV32, OP_STEM32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
+enum OpType { OP_CONV32, OP_STEM32, OP_C3K2F32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
 
 struct Op {
     OpType type;
@@ -58,6 +59,7 @@ struct Op {
     ConvLaunch conv;         // OP_CONV
     Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
     Stem32Launch stem32;     // OP_STEM32 (fp32 mode: network input layer as row stripes)
+    C3k2F32Launch c3k2f;     // OP_C3K2F32 (fp32 mode: Bottleneck + closing 1x1 of a C3k2 block in one launch)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     FrontLaunch front;       // OP_FRONT (model.0 + model.1 + model.2.cv1 in one launch)
     BneckLaunch bneck;       // OP_BNECK (fused Bottleneck over row stripes)
@@ -727,7 +729,38 @@ struct Builder {
         conv(name + ".cv1", in, H, W, sub(cat, 0, 2 * c));
         c3k2_rest(name, cat, c, H, W, out, n, use_c3k);
     }
+    // fp32 mode: Bottleneck (3x3, 3x3, shortcut) + closing 1x1 of a C3k2 block with one Bottleneck as ONE launch (c3k2f32.hip); false: not emitted
+    bool c3k2_f32(const std::string &name, int cat, int c, int H, int W, Slice out) {
+        if (!M.f32 || !M.tail || !M.o.c3k2f || out.buf < 0 || P.bufs[out.buf].virt || P.bufs[cat].blk32 || !c3k2f32_supported(c, out.C, H, W)) return false;
+        const ConvRecord *r1 = rec(name + ".m.0.cv1"), *r2 = rec(name + ".m.0.cv2"), *rc = rec(name + ".cv2");
+        if (!r1 || !r2 || !rc || err) return false;
+        auto is = [](const ConvRecord *q, int k, int c1, int c2) { return q->k == k && q->s == 1 && q->g == 1 && q->act && q->c1 == c1 && q->c2 == c2; };
+        if (!is(r1, 3, c, c / 2) || !is(r2, 3, c / 2, c) || !is(rc, 1, 3 * c, out.C)) return false;
+        const std::vector<int> perm = c3k2f32_cout_perm(out.C);
+        const Conv32Tiling t1{1, 1, c, 1, 1, 1, 1}, t2{1, 1, c / 2, 1, 1, 1, 1}, tc{1, 1, 3 * c, out.C / 16, 1, 1, 1};
+        std::vector<float> wall = pack_conv32_weights(r1->w, c / 2, c, 3, t1, nullptr, false);  // [W1 | W2 | WC | bc]: the kernel's LDS image
+        const std::vector<float> w2 = pack_conv32_weights(r2->w, c, c / 2, 3, t2, nullptr, false), wc = pack_conv32_weights(rc->w, out.C, 3 * c, 1, tc, perm.data(), false);
+        wall.insert(wall.end(), w2.begin(), w2.end());
+        wall.insert(wall.end(), wc.begin(), wc.end());
+        for (int i = 0; i < out.C; ++i) wall.push_back(rc->b[perm[i]]);
+        if (wall.size() != (size_t)(9 * 256 + 4 * 256 + 2 * 64 + (out.C / 16) * 3 * 256 + out.C)) { err = set_error(ctx, OBB_ERR_STATE, "c3k2 fp32 kernel: weight image has %zu floats", wall.size()); return false; }
+        std::vector<float> b1(64, 0.f), b2(64, 0.f);
+        for (int i = 0; i < c / 2; ++i) b1[i] = r1->b[i];
+        for (int i = 0; i < c; ++i) b2[i] = r2->b[i];
+        Op op;
+        op.type = OP_C3K2F32; op.name = name + ".m.0+" + name + ".cv2"; op.in = sub(cat, 0, 2 * c); op.out = out; op.H = H; op.W = W; op.Ho = H; op.Wo = W;
+        C3k2F32Launch &L = op.c3k2f;
+        L.H = H; L.W = W; L.C = c; L.CO = out.C;
+        L.w1 = upload(wall); L.b1 = upload(b1); L.b2 = upload(b2);
+        op.macs = (double)H * W * (9.0 * c * (c / 2) * 2 + 3.0 * c * out.C);
+        P.macs_per_img += op.macs;
+        P.ops.push_back(op);
+        P.named[name + ".cv2"] = out;
+        return true;
+    }
+
     void c3k2_rest(const std::string &name, int cat, int c, int H, int W, Slice out, int n, bool use_c3k) {
+        if (n == 1 && !use_c3k && c3k2_f32(name, cat, c, H, W, out)) return;
         if (n == 1 && !use_c3k && bottleneck(name + ".m.0", sub(cat, c, c), H, W, sub(cat, 2 * c, c), 0.5, (name + ".cv2").c_str(), sub(cat, 0, c), out)) return;
         if (n == 1 && !use_c3k) { conv(name + ".cv2", whole(cat), H, W, out); return; }
         for (int i = 0; i < n; ++i) {
@@ -1038,6 +1071,12 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_conv32(L, st);
                 break;
             }
+            case OP_C3K2F32: {
+                C3k2F32Launch L = op.c3k2f;
+                L.B = B; L.cat = tref(P, op.in, boff); L.out = tref(P, op.out, boff);
+                e = launch_c3k2f32(L, st);
+                break;
+            }
             case OP_STEM32: {
                 Stem32Launch L = op.stem32;
                 L.B = B; L.in = tiles; L.out = tref(P, op.out, boff);
@@ -1250,7 +1289,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"blk32", &ctx->opt.blk32}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"blk32", &ctx->opt.blk32}, {"c3k2f", &ctx->opt.c3k2f}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
@@ -1387,6 +1426,12 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_C3K2F32: {
+                int th, tw;
+                c3k2f32_tile(op.H, op.W, th, tw);
+                snprintf(line, sizeof line, "c3k2f32 %s c%d co%d out%dx%d TH%d TW%d macs%.0f\n", op.name.c_str(), op.c3k2f.C, op.c3k2f.CO, op.Ho, op.Wo, th, tw, op.macs);
+                break;
+            }
             case OP_STEM32:
                 snprintf(line, sizeof line, "stem32 %s k3 s2 cin%d cout%d out%dx%d rows%d macs%.0f\n", op.name.c_str(), op.stem32.cin, op.stem32.cout, op.Ho, op.Wo, 4, op.macs);
                 break;

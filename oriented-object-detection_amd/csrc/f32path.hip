@@ -781,7 +781,7 @@ static hipError_t launch32_f(const Conv32Launch &L, const C32Params &P, int tail
         return hipErrorInvalidValue;
     }
     if (L.up_c > 0) {
-        if constexpr (KS == 1 && WC == 4 && !BLK) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0>(P, grid, lds, st); }
+        if constexpr (KS == 1 && WC == 4) { if (!tail_wc2) return launch32_k<KS, MFM, WC, false, true, 0, false, 1, BLK>(P, grid, lds, st); }
         return hipErrorInvalidValue;
     }
     if (L.dw) {

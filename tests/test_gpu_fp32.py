@@ -86,8 +86,14 @@ def test_fp32_fused_forms_are_bit_identical(ood, nets, h, w, B):
     ops.model_load(net.to_blob(), precision="f32", stem=False)
     plan = ops.debug_plan(h, w)
     assert any(" tail64 " in l for l in plan) and any(" vcat1 " in l for l in plan) and any("|" in l for l in plan) and any("sppf" in l for l in plan), plan
+    assert sum(l.startswith("c3k2f32 ") for l in plan) == 1, plan  # Bottleneck + closing 1x1 of model.2 in one launch (c3k2f32.hip)
     fused = ops.forward(x).cpu()
+    x2_plain_vs = ops.debug_activation("model.2.cv2", B, h, w).cpu()
     assert torch.equal(fused[..., :77], plain[..., :77]), float((fused - plain)[..., :77].abs().max())
+    ops.model_load(net.to_blob(), precision="f32", stem=False, c3k2f=False)  # the block kernel alone off: its output tensor, bit for bit
+    assert not any(l.startswith("c3k2f32 ") for l in ops.debug_plan(h, w))
+    ops.forward(x)
+    assert torch.equal(ops.debug_activation("model.2.cv2", B, h, w).cpu(), x2_plain_vs)
     # two forms that sum in another order than what they replace: close, not identical
     # (a) the MFMA attention core vs the scalar one
     ops.model_load(net.to_blob(), precision="f32", attn_mfma=False, stem=False)

@@ -1342,8 +1342,11 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
         if (hipStreamIsCapturing((hipStream_t)s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) use_graph = false;
     }
     hipStream_t st = (hipStream_t)s;
-    for (int b0 = 0; b0 < B; b0 += max_mb) {
-        int nb = std::min<int>(max_mb, B - b0);
+    // (equal rounds: 10 764 tiles of 128 px are 2 x 5382, not 8192 + 2572 -- the short round ran its small-map layers at a third of the
+    // workgroups the chip holds)
+    const int nrounds = (B + max_mb - 1) / max_mb, per_round = (B + nrounds - 1) / nrounds;
+    for (int b0 = 0; b0 < B; b0 += per_round) {
+        int nb = std::min<int>(per_round, B - b0);
         const uint8_t *tp = tiles + (int64_t)b0 * h * w * ctx->model->ch;
         float *hp = head + (int64_t)b0 * P->A * P->no_pad;
         Plan::GraphKey key(nb, (const void *)tp, (void *)hp);

@@ -158,6 +158,7 @@ def main():
             self.ev_pre, self.ev_used = [None, None], [None, None]
             A = ops.model_info(px, px)["anchors"]
             self.heads = [torch.zeros((n, A, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
+            self.cmaxs = [torch.zeros((n, A), dtype=torch.float32, device=dev) for _ in range(2)]     # largest class logit per anchor (obb_forward_gate)
             self.rects_dev = torch.as_tensor(rects).to(dev)
             self.tile_ids = tile_ids
             self.cfg = D.Config(tile_sizes=(px,), overlaps=(100 if px > 128 else 30,))
@@ -183,7 +184,7 @@ def main():
                 self.ev_pre[k % 2] = None
                 src = self.tiles4[k % 2]
             e0.record()
-            head = ops.forward(src, out=self.heads[k % 2])
+            head = ops.forward(src, out=self.heads[k % 2], cmax=self.cmaxs[k % 2])
             e1.record()
             if self.tiles4 is not None:
                 self.ev_used[k % 2] = e1
@@ -195,7 +196,8 @@ def main():
         def records(self, head):  # on s_post: decode -> Fast-NMS -> results -> border filter -> per-tile merge -> exchange records
             self.model._ensure_active()
             md = self.cfg.max_det
-            det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md, zero=False)
+            cmax = self.cmaxs[0] if head.data_ptr() == self.heads[0].data_ptr() else self.cmaxs[1]
+            det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md, zero=False, cmax=cmax)
             margin = self.cfg.margin_for(self.px) if self.cfg.APPLY_BORDER_FILTER else 0
             rec, _, n = ops.tile_survivors(det, cnt, None, self.tile_ids, self.rects_dev, margin, self.cfg.iou_threshold, self.cfg.strike_cls)
             return D.TileRecords.from_packed(rec, n)  # packed rows + their count, both still on the device

@@ -198,6 +198,10 @@ int obb_model_info(const obb_ctx *ctx, int32_t h, int32_t w, int32_t *nc, int32_
  * 4x16 DFL logits, nc class logits, 1 angle logit, zero padding).  Preprocess (BGR->RGB, /255; Appendix A2) is fused
  * into the first convolution. */
 int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s);
+/* The same forward, which also leaves cmax float[B][A] = the largest class logit of every anchor (a dense tensor: the confidence gate of
+ * obb_decode_nms_gate then reads 4 bytes per anchor instead of a 48-byte piece of every 320-byte head row).  Written by the fused class
+ * tails of the head where the plan has them, by one extra pass over the head rows otherwise.  cmax NULL = obb_forward. */
+int obb_forward_gate(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, float *cmax, obb_stream_t s);
 /* Debug: text dump of the lowered forward for an (h, w) input -- one line per kernel launch (layer name, tiling,
  * grid, LDS bytes, MACs).  buf_host may be NULL to query *needed. */
 int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf_host, int64_t buf_bytes, int64_t *needed);
@@ -210,6 +214,10 @@ int obb_debug_activation(obb_ctx *ctx, int32_t h, int32_t w, int32_t B, const ch
  * out float[B*max_det*7] rows (x, y, w, h, conf, cls, theta) in score order; count int32[B]. */
 int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres,
                    int32_t max_det, float *out, int32_t *count, obb_stream_t s);
+/* obb_decode_nms with the candidate gate read from cmax (obb_forward_gate's output for the SAME head tensor; NULL = obb_decode_nms): the
+ * exact class scores are still taken from the head rows of the anchors that pass, so the result is identical. */
+int obb_decode_nms_gate(obb_ctx *ctx, const float *head, const float *cmax, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres,
+                        int32_t max_det, float *det, int32_t *count, obb_stream_t s);
 /* The same function in its full form (decode every anchor, then NMS sized for all of them): an independent implementation kept for the
  * parity tests, which require obb_decode_nms (candidate-first: conf filter on the class logits, decode + NMS of the survivors only) to
  * return the same rows bit for bit. */

@@ -48,9 +48,11 @@ SIGNATURES = {
     "obb_model_unload": [_V, C.c_int32],
     "obb_model_info": [_V, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip],
     "obb_forward": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V],
+    "obb_forward_gate": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, _V],
     "obb_debug_plan": [_V, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, c_lp],
     "obb_debug_activation": [_V, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, _V, C.c_int64, c_lp, c_ip, _V],
     "obb_decode_nms": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _V, _V, _V],
+    "obb_decode_nms_gate": [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _V, _V, _V],
     "obb_decode_nms_full": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _V, _V, _V],
     "obb_decode": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V],
     "obb_probiou_nms": [_V, _V, _V, C.c_int64, C.c_float, _V, _V, _V],

@@ -349,7 +349,7 @@ __device__ __forceinline__ void class_best(const float *__restrict__ cp, int nc,
 }
 
 template <bool WIDE /* nc <= 16: vector loads */>
-__global__ __launch_bounds__(256) void k_cand_nms(const float *__restrict__ head, int A, int nc, int h, int w, float conf_thres, float logit_gate,
+__global__ __launch_bounds__(256) void k_cand_nms(const float *__restrict__ head, const float *__restrict__ cmax, int A, int nc, int h, int w, float conf_thres, float logit_gate,
                                                  float iou_thres, int max_det, float kq, float bdmax, HeavyScratch S, float *__restrict__ out,
                                                  int32_t *__restrict__ count) {
     __shared__ int wave_tot[16];
@@ -375,7 +375,9 @@ __global__ __launch_bounds__(256) void k_cand_nms(const float *__restrict__ head
         int bj = 0;
         if (a < A) {
             const float *cp = hb + (int64_t)a * no + 4 * kRegMaxD;
-            if constexpr (WIDE) class_best(cp, nc, logit_gate, best, bj);
+            // (cmax: the forward's per-anchor maximum of these logits, dense -- 4 bytes per anchor instead of a 48-byte piece of every
+            // 320-byte row; the rows of the few anchors above the gate are then read as before: the same values, the same decisions)
+            if constexpr (WIDE) { if (!cmax || cmax[(int64_t)b * A + a] > logit_gate) class_best(cp, nc, logit_gate, best, bj); }
             else {
                 float mx = -INFINITY;
                 for (int j = 0; j < nc; ++j) mx = fmaxf(mx, cp[j]);
@@ -805,6 +807,11 @@ int obb_decode(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w,
 
 int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres, int32_t max_det,
                    float *out, int32_t *count, obb_stream_t s) {
+    return obb_decode_nms_gate(ctx, head, nullptr, B, h, w, conf_thres, iou_thres, max_det, out, count, s);
+}
+
+int obb_decode_nms_gate(obb_ctx *ctx, const float *head, const float *cmax, int32_t B, int32_t h, int32_t w, float conf_thres, float iou_thres, int32_t max_det,
+                        float *out, int32_t *count, obb_stream_t s) {
     OBB_REQUIRE(ctx, ctx && B >= 0 && max_det > 0, "obb_decode_nms: bad arguments");
     int32_t nc = 0, A = 0;
     int rc = obb_model_info(ctx, h, w, &nc, nullptr, &A, nullptr);
@@ -834,8 +841,8 @@ int obb_decode_nms(obb_ctx *ctx, const float *head, int32_t B, int32_t h, int32_
         gate = (float)(L - 1e-3 - 1e-4 * fabs(L));
     } else if (conf_thres >= 1.0f) gate = INFINITY;
     const float kq = far_apart_factor(iou_thres), bdmax = probiou_bdmax(iou_thres);
-    if (nc <= 16) hipLaunchKernelGGL(k_cand_nms<true>, dim3((unsigned)B), dim3(256), 0, st, head, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
-    else hipLaunchKernelGGL(k_cand_nms<false>, dim3((unsigned)B), dim3(256), 0, st, head, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
+    if (nc <= 16) hipLaunchKernelGGL(k_cand_nms<true>, dim3((unsigned)B), dim3(256), 0, st, head, cmax, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
+    else hipLaunchKernelGGL(k_cand_nms<false>, dim3((unsigned)B), dim3(256), 0, st, head, (const float *)nullptr, A, nc, h, w, conf_thres, gate, iou_thres, max_det, kq, bdmax, S, out, count);
     OBB_LAUNCH_CHECK(ctx);
     // tiles above kCandCap candidates (device-side list; every block of these launches exits at once when the list is empty)
     const int slots = std::min<int>(kHeavySlots, B);

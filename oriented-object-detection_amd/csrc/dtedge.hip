@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64) void k_dt_chamfer(const uint8_t *__restrict__ e
 // Arithmetic as the reference's pinned numpy 1.26.4 runs it (Detect_OBB.py:126-133): lo / hi are float64 SCALARS, and a float32 array
 // combined with a float64 scalar stays float32 there (value-based casting; numpy >= 2 would promote), so every step below is one
 // correctly rounded float32 operation (no contraction: the build uses -ffp-contract=off).  exp: float32(exp64(x)) with exp64 the degree-14
-// Taylor polynomial in Horner form, double multiply + add per step -- the same IEEE operations as oracle/dtedge.py::exp32, hence the
+// Taylor polynomial in Horner form, double multiply + add per step -- the same IEEE operations as the CPU oracle (dtedge.py: exp32), hence the
 // same bytes; numpy's own float32 SIMD exp may differ from it by an ulp (unpinned).
 __device__ __forceinline__ float dt_exp32(float xf) {  // xf in [-0.5, 0]
     constexpr double C[15] = {1.0, 1.0, 1.0 / 2.0, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0,

@@ -74,6 +74,7 @@ struct Op {
     int act = 0;
     int N = 0, nh = 0, kd = 0, hd = 0;  // OP_ATTN
     int head_level = -1;     // >= 0: output goes to the caller's head tensor at this level
+    bool emit_cmax = false;  // this launch writes the class logits of its level through a fused tail: it can emit their per-anchor maximum too
     int lane = 0;            // 0 = caller's stream; 1..3 = side stream of a head branch (box / class / angle)
     int wait_feat = -1;      // >= 0: first op of a head branch at this pyramid level: wait until its input feature map exists
     int signal_feat = -1;    // >= 0: this op produces the feature map of that pyramid level
@@ -86,6 +87,7 @@ struct Plan {
     std::map<std::string, Slice> named;
     std::vector<void *> dev_allocs;
     int lvl_off[3] = {0, 0, 0};
+    int cmax_mask = 0;  // levels whose class-logit maximum is written by the forward itself (the others: k_class_max behind it)
     int cap = 0;
     void *slab = nullptr;
     int64_t bytes_per_img = 0;
@@ -95,7 +97,7 @@ struct Plan {
     static constexpr int kLanes = 4;
     hipStream_t lanes[kLanes] = {};
     hipEvent_t ev_feat[kLanes] = {}, ev_done[kLanes] = {};
-    typedef std::tuple<int, const void *, void *> GraphKey;
+    typedef std::tuple<int, const void *, void *, void *> GraphKey;  // (sub-batch, tiles, head, class-logit maxima or nullptr)
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> seen;
     std::vector<GraphKey> graph_order;  // insertion order of `graphs` (eviction)
@@ -371,6 +373,7 @@ struct Builder {
                 L.tail_b = upload(b2);
                 L.tail_cout = r2->c2; L.tail_act = r2->act;
                 op.name = name + "+" + tail_name;
+                if (head_level >= 0 && out.buf == -2 && out.co == 4 * kRegMax && r2->c2 <= 16 && !r2->act) { op.emit_cmax = true; P.cmax_mask |= 1 << head_level; }
                 op.macs += (double)op.Ho * op.Wo * r2->c2 * r->c2;
                 P.macs_per_img += op.macs;
                 P.ops.push_back(op);
@@ -499,6 +502,7 @@ struct Builder {
             for (int c = 0; c < rt->c2; ++c) b2[c] = rt->b[c];
             L.tail_b = upload(b2);
             L.tail_cout = rt->c2; L.tail_act = 0;
+            if (out.buf == -2 && out.co == 4 * kRegMax) { op.emit_cmax = true; P.cmax_mask |= 1 << head_level; }
             op.macs += (double)H * W * rt->c1 * rt->c2;
         }
         P.macs_per_img += op.macs;
@@ -1029,11 +1033,21 @@ static int get_plan(obb_ctx *ctx, int h, int w, Plan **out) {
     return OBB_OK;
 }
 
+// per-anchor maximum of the class logits (the gate of obb_decode_nms_gate) for plans whose class tails are not fused
+__global__ __launch_bounds__(256) void k_class_max(const float *__restrict__ head, int64_t n, int no_pad, int c0, int nc, float *__restrict__ cmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = head + i * no_pad + c0;
+    float m = -INFINITY;
+    for (int j = 0; j < nc; ++j) m = fmaxf(m, r[j]);
+    cmax[i] = m;
+}
+
 // One sub-batch: images [boff, boff + B) of every activation buffer, all launches on `st`.
 // (Measured and dropped: walking the HBM-bound stride-2 .. stride-8 front of the network in slices of 32 .. 256 tiles so that a layer's
 //  output is still in the 256 MiB Infinity Cache when the next layer reads it: 9.41 ms per 1024 tiles without, 9.96 / 9.55 / 9.39 / 9.37 ms
 //  with slices of 32 / 64 / 128 / 256.)
-static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t st, int boff) {
+static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, float *cmax, hipStream_t st, int boff) {
     Model &M = *ctx->model;
     for (Op &op : P.ops) {
         hipError_t e = hipSuccess;
@@ -1061,6 +1075,7 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                     if (op.one_d && o.cpb) o_hw = op.Ho * op.Wo;  // channel-blocked per image: the flattened pixel row is split back into (image, pixel)
                 }
                 if (L.tail_cout > 0) { L.tail_out = o; L.tail_out_hw = o_hw; }
+                if (cmax && op.emit_cmax) { L.cmax = cmax + P.lvl_off[op.head_level]; L.cmax_bs = P.A; }
                 else { L.out = o; L.out_hw = o_hw; }
                 L.res = tref(P, op.res, boff);
                 if (op.one_d) {  // 1x1: batch x pixels is one dense pixel row
@@ -1176,6 +1191,11 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
         }
         if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
     }
+    if (cmax && P.cmax_mask != 7) {  // a plan without the fused class tails (16-bit modes, "tail" = 0, small maps): one pass over the head rows
+        const int64_t n = (int64_t)B * P.A;
+        hipLaunchKernelGGL(k_class_max, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const float *)head, n, P.no_pad, 4 * kRegMax, M.nc, cmax);
+        if (hipGetLastError() != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "forward: launch of the class-maximum pass failed");
+    }
     return OBB_OK;
 }
 
@@ -1185,11 +1205,11 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
 // "fwd_split" 0 (default) = 2 chains: caller stream + side streams + one more user stream still fit the 4 hardware queues.  (3 / 4
 // chains, 1024-tile bench steps: fp16 8.82 -> 9.86 / 10.58 ms; fp32 within the run-to-run noise of 2 -- 34.99 vs 36.05 on one box,
 // 35.52 vs 35.14 on the next.)
-static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, hipStream_t main_st) {
+static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *head, float *cmax, hipStream_t main_st) {
     Model &M = *ctx->model;
     const int nsplit_cfg = ctx->opt.fwd_split > 0 ? std::min(Plan::kLanes, ctx->opt.fwd_split) : 2;
     int ns = (B >= 32 * nsplit_cfg) ? nsplit_cfg : 1;
-    if (ns == 1) return run_forward(ctx, P, tiles, B, head, main_st, 0);
+    if (ns == 1) return run_forward(ctx, P, tiles, B, head, cmax, main_st, 0);
     if (!P.lanes[0]) {
         for (int i = 0; i < Plan::kLanes; ++i) {
             OBB_HIP(ctx, hipStreamCreateWithFlags(&P.lanes[i], hipStreamNonBlocking));
@@ -1201,7 +1221,7 @@ static int run_round(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float *
     for (int i = 0; i < ns; ++i) {
         int lo = (int)((int64_t)B * i / ns), hi = (int)((int64_t)B * (i + 1) / ns);
         OBB_HIP(ctx, hipStreamWaitEvent(P.lanes[i], P.ev_feat[0], 0));
-        int rc = run_forward(ctx, P, tiles + (int64_t)lo * P.h * P.w * M.ch, hi - lo, head + (int64_t)lo * P.A * P.no_pad, P.lanes[i], lo);
+        int rc = run_forward(ctx, P, tiles + (int64_t)lo * P.h * P.w * M.ch, hi - lo, head + (int64_t)lo * P.A * P.no_pad, cmax ? cmax + (int64_t)lo * P.A : nullptr, P.lanes[i], lo);
         if (rc) return rc;
         OBB_HIP(ctx, hipEventRecord(P.ev_done[i], P.lanes[i]));
     }
@@ -1323,6 +1343,10 @@ int obb_model_info(const obb_ctx *cctx, int32_t h, int32_t w, int32_t *nc, int32
 }
 
 int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, obb_stream_t s) {
+    return obb_forward_gate(ctx, tiles, B, h, w, head, nullptr, s);
+}
+
+int obb_forward_gate(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_t w, float *head, float *cmax, obb_stream_t s) {
     OBB_REQUIRE(ctx, ctx && B >= 0, "obb_forward: bad arguments");
     if (B == 0) return OBB_OK;
     OBB_REQUIRE(ctx, tiles && head, "obb_forward: NULL buffer");
@@ -1349,7 +1373,8 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
         int nb = std::min<int>(per_round, B - b0);
         const uint8_t *tp = tiles + (int64_t)b0 * h * w * ctx->model->ch;
         float *hp = head + (int64_t)b0 * P->A * P->no_pad;
-        Plan::GraphKey key(nb, (const void *)tp, (void *)hp);
+        float *cp = cmax ? cmax + (int64_t)b0 * P->A : nullptr;
+        Plan::GraphKey key(nb, (const void *)tp, (void *)hp, (void *)cp);
         auto git = P->graphs.find(key);
         if (use_graph && git != P->graphs.end()) {
             OBB_HIP(ctx, hipGraphLaunch(git->second, st));
@@ -1366,7 +1391,7 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
             }
         }
         if (capture && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); capture = false; }
-        rc = run_round(ctx, *P, tp, nb, hp, st);
+        rc = run_round(ctx, *P, tp, nb, hp, cp, st);
         if (capture) {
             hipGraph_t g = nullptr;
             hipError_t e = hipStreamEndCapture(st, &g);
@@ -1383,7 +1408,7 @@ int obb_forward(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, int32_
             }
             (void)hipGetLastError();
             if (rc) return rc;
-            rc = run_round(ctx, *P, tp, nb, hp, st);  // capture unavailable: run eagerly
+            rc = run_round(ctx, *P, tp, nb, hp, cp, st);  // capture unavailable: run eagerly
         }
         if (rc) return rc;
     }

@@ -34,6 +34,10 @@ struct Conv32Launch {
     int tail_cout = 0, tail_act = 0;
     TensorRef tail_out;
     int tail_out_hw = 0;
+    // (TAIL writing the class logits of the head) per-anchor maximum of the tail's outputs, dense float[image][cmax_bs] + cmax_off: the
+    // candidate gate of obb_decode_nms_gate reads 4 bytes per anchor instead of a 48-byte piece of every 320-byte head row
+    float *cmax = nullptr;
+    int64_t cmax_bs = 0;
     // tiling (plan_conv32): output tile TH x TW (<= 16 * (8 / WC) * MFM pixels), CK input channels per LDS stage, WC of the workgroup's 8
     // waves along cout (16 couts each), the other 8 / WC along the pixel fragments, MFM fragments of 16 pixels per wave
     int TH = 1, TW = 208, CK = 16, WC = 4, MFM = 7;

@@ -38,6 +38,7 @@ struct C32Params {
     const float *res; int64_t res_bs; int res_cs, res_co;
     const float *wpk, *bias, *lut;
     const float *w2, *b2; float *out2; int64_t out2_bs; int out2_cs, out2_co, out2_hw, cout2, act2, kst2;  // TAIL: fused trailing 1x1
+    float *cmax; int64_t cmax_bs;  // TAIL = 1 over the class logits: per-anchor maximum of the tail's outputs (nullptr: none)
     int Hin, Win, Hout, Wout, cin, cout, stride, act, flip_bgr;
     int TH, TW, CK, sh /*log2(CK/4)*/, tiles_x, tiles_y, ntiles, nstage, kst, out_hw, ncb;
     int krem, wcb;  // 4-channel chunks of a stage beyond the kst whole pieces (0..3: one MFMA each); bytes of one cout fragment's stage weights
@@ -465,8 +466,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
                     if (wp2 + WP2 * i < cur.nfrag1) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a[i][s], acc2[i], 0, 0, 0);
         }
         const int c2 = wc2 * 16 + g * 4;
-        if (c2 >= P.cout2) return;
-        const float4 bv2 = *reinterpret_cast<const float4 *>(P.b2 + c2);
+        const bool lane_on = c2 < P.cout2;
+        if (!lane_on && !(TAIL == 1 && P.cmax)) return;  // (with the class-logit maximum on, the four lanes of a pixel stay together for the shuffles)
+        const float4 bv2 = *reinterpret_cast<const float4 *>(P.b2 + (lane_on ? c2 : 0));
         const bool full2 = c2 + 4 <= P.cout2;
 #pragma unroll
         for (int i = 0; i < MFM2; ++i) {
@@ -485,6 +487,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_conv_f32(const C32Params P)
             }
             int64_t ob = cur.b + il, opx = opix;
             if (P.out2_hw > 0) { ob = opx / P.out2_hw; opx -= ob * P.out2_hw; }
+            if constexpr (TAIL == 1) {
+                if (P.cmax) {  // max over the tail's cout2 outputs of this pixel: own four, then the pixel's other lanes (lane ^ 16, lane ^ 32)
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c2 + j < P.cout2) m = fmaxf(m, v[j]);
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    if (g == 0) P.cmax[ob * P.cmax_bs + opx] = m;
+                    if (!lane_on) continue;
+                }
+            }
             float *op = P.out2 + ob * P.out2_bs + opx * P.out2_cs + P.out2_co + c2;
             if (full2 && ((P.out2_cs | P.out2_co) & 3) == 0) {
                 *reinterpret_cast<float4 *>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -911,6 +925,10 @@ hipError_t launch_conv32(const Conv32Launch &L, hipStream_t st) {
         if (L.WC == 2 && tail_wc2 != 2) { if (tail_wc2 == 1) tail_wc2 = 2; else return hipErrorInvalidValue; }  // (a 16-cout tail behind a 32-cout layer: the second fragment is empty)
         P.w2 = L.tail_w; P.b2 = L.tail_b; P.out2 = (float *)L.tail_out.p; P.out2_bs = L.tail_out.bs; P.out2_cs = L.tail_out.cs; P.out2_co = L.tail_out.co;
         P.out2_hw = L.tail_out_hw; P.cout2 = L.tail_cout; P.act2 = L.tail_act; P.kst2 = L.cout / 16;
+        if (L.cmax) {
+            if (tail_wc2 != 1 || L.tail_act) return hipErrorInvalidValue;  // (one cout fragment holds all the logits; plain outputs)
+            P.cmax = L.cmax; P.cmax_bs = L.cmax_bs;
+        }
     }
     P.tstep = L.xtile ? 1 : 0;
 #ifdef OBB_DIAG

@@ -138,8 +138,9 @@ class YOLO:
         """tiles uint8 [B,h,w,ch] on device, already letterboxed -> (det [B,max_det,7] (x,y,w,h,conf,cls,theta), count [B])"""
         self._ensure_active()
         B, h, w, ch = tiles.shape
-        head = ops.forward(tiles)
-        return ops.decode_nms(head, h, w, conf, iou, max_det, zero=zero)
+        cmax = torch.empty((B, ops.model_info(h, w, tiles.device)["anchors"]), dtype=torch.float32, device=tiles.device)
+        head = ops.forward(tiles, cmax=cmax)  # (cmax: the largest class logit per anchor -- the dense candidate gate of the NMS kernel)
+        return ops.decode_nms(head, h, w, conf, iou, max_det, zero=zero, cmax=cmax)
 
     # ------------------------------------------------------------------ Ultralytics-shaped API
     def __call__(self, source, conf=0.25, iou=0.7, max_det=300, **kwargs):

@@ -167,6 +167,12 @@ def _forward(tiles: T, head: T) -> None:
     _call("obb_forward", ctx(tiles.device), _p(tiles), B, h, w, _p(head), _stream())
 
 
+@_op("forward_gate", ("head", "cmax"))
+def _forward_gate(tiles: T, head: T, cmax: T) -> None:
+    B, h, w, _ = tiles.shape
+    _call("obb_forward_gate", ctx(tiles.device), _p(tiles), B, h, w, _p(head), _p(cmax), _stream())
+
+
 @_op("decode", ("pred",))
 def _decode(head: T, h: int, w: int, pred: T) -> None:
     _call("obb_decode", ctx(head.device), _p(head), head.shape[0], h, w, _p(pred), _stream())
@@ -175,6 +181,11 @@ def _decode(head: T, h: int, w: int, pred: T) -> None:
 @_op("decode_nms", ("det", "count"))
 def _decode_nms(head: T, h: int, w: int, conf: float, iou: float, max_det: int, det: T, count: T) -> None:
     _call("obb_decode_nms", ctx(head.device), _p(head), head.shape[0], h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
+
+
+@_op("decode_nms_gate", ("det", "count"))
+def _decode_nms_gate(head: T, cmax: T, h: int, w: int, conf: float, iou: float, max_det: int, det: T, count: T) -> None:
+    _call("obb_decode_nms_gate", ctx(head.device), _p(head), _p(cmax), head.shape[0], h, w, float(conf), float(iou), int(max_det), _p(det), _p(count), _stream())
 
 
 @_op("decode_nms_full", ("det", "count"))
@@ -521,9 +532,11 @@ def model_info(h, w, device=None):
     return {"nc": nc.value, "ch": ch.value, "anchors": a.value, "nconv": n.value}
 
 
-def forward(tiles, out=None):
+def forward(tiles, out=None, cmax=None):
     """tiles uint8 [B,h,w,ch] NHWC (BGR for 3-channel input, as the reference passes crops) -> raw head [B,A,NO] f32.
-    `out`: optional preallocated head tensor (stable input/output addresses let the library replay its captured hipGraph)."""
+    `out`: optional preallocated head tensor (stable input/output addresses let the library replay its captured hipGraph).
+    `cmax`: optional float32 [B,A] that receives the largest class logit of every anchor (the dense candidate gate of
+    decode_nms(..., cmax=...): obb_forward_gate)."""
     t = _chk(tiles, torch.uint8, "tiles")
     B, h, w, ch = t.shape
     info = model_info(h, w, t.device)
@@ -537,7 +550,13 @@ def forward(tiles, out=None):
         head = _chk(out, torch.float32, "out")
     else:
         head = torch.zeros(shape, dtype=torch.float32, device=t.device)
-    if B:
+    if cmax is not None:
+        cm = _chk(cmax, torch.float32, "cmax")
+        if tuple(cm.shape) != shape[:2]:
+            raise ValueError(f"forward: cmax must have shape {shape[:2]}")
+        if B:
+            _O.forward_gate(t, head, cm)
+    elif B:
         _O.forward(t, head)
     return head  # rows padded to a multiple of 4 floats; [..., :64+nc+1] are the logits
 
@@ -581,7 +600,7 @@ def decode(head, h, w):
     return pred
 
 
-def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False, zero=True):
+def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False, zero=True, cmax=None):
     """-> (det [B,max_det,7] rows (x,y,w,h,conf,cls,theta) in score order, count int32[B]).  full=True runs the reference form (decode
     every anchor first) that the candidate-first default must reproduce bit for bit.  zero=False leaves the rows past count[b]
     uninitialised (no fill launch: what the device-side consumers, which only look at rows below the count, ask for)."""
@@ -589,7 +608,12 @@ def decode_nms(head, h, w, conf=0.25, iou=0.7, max_det=300, full=False, zero=Tru
     B = hd.shape[0]
     det = (torch.zeros if zero or not B else torch.empty)((B, max_det, 7), dtype=torch.float32, device=hd.device)
     count = (torch.zeros if zero or not B else torch.empty)(B, dtype=torch.int32, device=hd.device)
-    if B:
+    if B and cmax is not None and not full:
+        cm = _chk(cmax, torch.float32, "cmax")
+        if tuple(cm.shape) != tuple(hd.shape[:2]):
+            raise ValueError("decode_nms: cmax must be [B, A] of the same head")
+        _O.decode_nms_gate(hd, cm, h, w, float(conf), float(iou), int(max_det), det, count)
+    elif B:
         (_O.decode_nms_full if full else _O.decode_nms)(hd, h, w, float(conf), float(iou), int(max_det), det, count)
     return det, count
 

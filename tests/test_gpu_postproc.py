@@ -84,6 +84,29 @@ def test_candidate_first_path_equals_the_full_decode(ops, net, conf, max_det):
         assert ncand.min() == 0 and ncand.max() > 2048 and ((ncand > 0) & (ncand <= 256)).any() and ((ncand > 256) & (ncand < 2048)).any()
 
 
+@pytest.mark.parametrize("precision,h,w,B", [("f32", 416, 416, 6), ("f32", 128, 128, 40), ("f32", 416, 288, 3), ("f16", 416, 416, 4)])
+def test_forward_gate_emits_the_class_maximum_and_decode_nms_gate_is_identical(ops, net, precision, h, w, B):
+    """obb_forward_gate leaves cmax[b, a] = max over the class logits of head[b, a] (written by the fused class tails of the fp32 head -- DWConv
+    prologue + 1x1 + tail at the levels of >= 112 pixels, the plain tail form on the small maps -- or by the extra pass of plans without them:
+    the 16-bit modes), EXACTLY the maximum of the stored logits; obb_decode_nms_gate, which gates the candidates on that dense tensor,
+    returns the rows of obb_decode_nms bit for bit -- also at a confidence where hundreds of anchors pass."""
+    import numpy as np
+    ops.model_load(net.to_blob(), precision=precision)
+    x = torch.as_tensor(np.random.default_rng(h + B).integers(0, 256, (B, h, w, 3), dtype=np.uint8)).cuda()
+    A = ops.model_info(h, w)["anchors"]
+    cmax = torch.full((B, A), float("nan"), device="cuda")
+    head = ops.forward(x, cmax=cmax)
+    assert torch.equal(head, ops.forward(x))                                  # the head itself is unchanged
+    assert torch.equal(cmax, head[..., 64:76].amax(-1)), float((cmax - head[..., 64:76].amax(-1)).abs().max())
+    for conf in (0.25, 0.001):
+        det, cnt = ops.decode_nms(head, h, w, conf, 0.7, 300)
+        det_g, cnt_g = ops.decode_nms(head, h, w, conf, 0.7, 300, cmax=cmax)
+        assert torch.equal(cnt, cnt_g) and int(cnt.sum()) > 0
+        for b in range(B):
+            assert torch.equal(det[b, :int(cnt[b])], det_g[b, :int(cnt[b])]), (conf, b)
+    ops.model_load(net.to_blob())  # (the module's default again)
+
+
 def test_probiou_nms_keep_mask_vs_oracle(ops):
     rng = np.random.default_rng(0)
     for n in (1, 7, 300, 2000):

@@ -1,8 +1,9 @@
-"""Copies the artifacts of tools/profile_all.sh (gpurun_out/final) into profiles/ (round-3 names) and prints the figures the docs quote.
+"""Copies the artifacts of tools/profile_all.sh (gpurun_out/final) into profiles/ (names prefixed with the round: r04_ by default, argv[2]) and prints the figures the docs quote.
 Parts that were not collected (a PART of profile_all.sh not run) are skipped."""
 import collections, csv, glob, json, os, shutil, sys
 O = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
-R = "profiles/r03_"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+R = "profiles/" + ROUND + "_"
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 KER = ("obb::k_conv", "k_dwconv3", "k_maxpool5", "k_upsample2", "k_attention", "k_stem_conv", "k_front", "k_sppf_pools", "k_bneck_stripe", "k_c3k_image", "k_dwpw_stripe", "_f32")
 
@@ -53,7 +54,7 @@ for tag, fdir, wdir, dst in (("fp32", "/pmc_fetch32", "/pmc_write32", "forward_f
         tr += r
         tw += w
         lines.append("%-78s read_x2_MB %8.1f write_MB %8.1f" % (o[:78], r, w))
-    hdr = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), one forward of B=256 tiles 416x416x3, %s arithmetic, MI355X (round-3 build)" % tag,
+    hdr = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), one forward of B=256 tiles 416x416x3, %s arithmetic, MI355X (%s build)" % (tag, ROUND),
            "# FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md section HBM); counters are in KiB",
            "# forward total: read %.2f GB (x2 corrected), write %.2f GB -> %.1f MB / tile" % (tr / 1e3, tw / 1e3, (tr + tw) / 256)]
     open(R + dst, "w").write("\n".join(hdr + lines) + "\n")

@@ -43,7 +43,8 @@ print("# post-processing kernels, MI355X, HIP-event time per call; bytes = ALGOR
 m = YOLO(make_weights.ensure("n", 12, 3, 0), imgsz=416)
 B, A = 1024, 3549
 tiles = torch.as_tensor(np.random.default_rng(0).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)).cuda()
-head = ops.forward(tiles)
+cmax = torch.empty((B, A), dtype=torch.float32, device="cuda")
+head = ops.forward(tiles, cmax=cmax)  # cmax: the largest class logit per anchor, written by the head's fused class tails (obb_forward_gate)
 torch.cuda.synchronize()
 pred = ops.decode(head[:64].contiguous(), 416, 416)
 conf = pred[..., 4:16].amax(-1)
@@ -55,9 +56,11 @@ for c in (0.25, 0.001):
     # decode reads 77 logits and writes 17 values per anchor; NMS reads 28 B per candidate; the candidate-first kernel reads
     # the class logits of every anchor (48 B) and whole rows of the survivors only
     row(f"obb_decode_nms  1024 tiles x 3549 anchors  conf {c}", us, B * A * (77 + 17) * 4, f"kept/tile {ncand:.1f}; bytes the candidate-first kernel needs: {B * A * 48 / 1e6:.0f} MB")
+    us = t_us(lambda: ops.decode_nms(head, 416, 416, c, 0.7, 300, cmax=cmax), reps=10)
+    row(f"obb_decode_nms_gate (dense class-maximum gate)  conf {c}", us, B * A * (77 + 17) * 4, f"bytes this form needs: {B * A * 4 / 1e6:.0f} MB of maxima + the rows of the candidates")
 us = t_us(lambda: ops.decode(head, 416, 416), reps=10)
 row("obb_decode (full decode, parity tap)  1024 tiles", us, B * A * (77 + 17) * 4)
-del head, tiles, pred
+del head, tiles, pred, cmax
 m.close()
 
 npair = 1 << 22

@@ -159,6 +159,7 @@ def main():
             A = ops.model_info(px, px)["anchors"]
             self.heads = [torch.zeros((n, A, 80), dtype=torch.float32, device=dev) for _ in range(2)]  # stable addresses -> hipGraph replay
             self.cmaxs = [torch.zeros((n, A), dtype=torch.float32, device=dev) for _ in range(2)]     # largest class logit per anchor (obb_forward_gate)
+            self.gate = model.precision in ("f32", "fp32")  # (the fp32 plan writes the maxima in its fused class tails; 16-bit plans would need an extra pass)
             self.rects_dev = torch.as_tensor(rects).to(dev)
             self.tile_ids = tile_ids
             self.cfg = D.Config(tile_sizes=(px,), overlaps=(100 if px > 128 else 30,))
@@ -184,7 +185,7 @@ def main():
                 self.ev_pre[k % 2] = None
                 src = self.tiles4[k % 2]
             e0.record()
-            head = ops.forward(src, out=self.heads[k % 2], cmax=self.cmaxs[k % 2])
+            head = ops.forward(src, out=self.heads[k % 2], cmax=self.cmaxs[k % 2] if self.gate else None)
             e1.record()
             if self.tiles4 is not None:
                 self.ev_used[k % 2] = e1
@@ -196,7 +197,7 @@ def main():
         def records(self, head):  # on s_post: decode -> Fast-NMS -> results -> border filter -> per-tile merge -> exchange records
             self.model._ensure_active()
             md = self.cfg.max_det
-            cmax = self.cmaxs[0] if head.data_ptr() == self.heads[0].data_ptr() else self.cmaxs[1]
+            cmax = None if not self.gate else (self.cmaxs[0] if head.data_ptr() == self.heads[0].data_ptr() else self.cmaxs[1])
             det, cnt = ops.decode_nms(head, self.px, self.px, self.cfg.conf_predict, self.cfg.iou_nms, md, zero=False, cmax=cmax)
             margin = self.cfg.margin_for(self.px) if self.cfg.APPLY_BORDER_FILTER else 0
             rec, _, n = ops.tile_survivors(det, cnt, None, self.tile_ids, self.rects_dev, margin, self.cfg.iou_threshold, self.cfg.strike_cls)

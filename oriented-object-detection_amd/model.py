@@ -138,8 +138,12 @@ class YOLO:
         """tiles uint8 [B,h,w,ch] on device, already letterboxed -> (det [B,max_det,7] (x,y,w,h,conf,cls,theta), count [B])"""
         self._ensure_active()
         B, h, w, ch = tiles.shape
-        cmax = torch.empty((B, ops.model_info(h, w, tiles.device)["anchors"]), dtype=torch.float32, device=tiles.device)
-        head = ops.forward(tiles, cmax=cmax)  # (cmax: the largest class logit per anchor -- the dense candidate gate of the NMS kernel)
+        # cmax: the largest class logit per anchor -- the dense candidate gate of the NMS kernel.  Only the fp32 plan writes it inside its
+        # fused class tails; the 16-bit plans would pay an extra pass over the head rows for it (measured: +0.15 ms per 1024 tiles)
+        cmax = None
+        if self.precision in ("f32", "fp32"):
+            cmax = torch.empty((B, ops.model_info(h, w, tiles.device)["anchors"]), dtype=torch.float32, device=tiles.device)
+        head = ops.forward(tiles, cmax=cmax)
         return ops.decode_nms(head, h, w, conf, iou, max_det, zero=zero, cmax=cmax)
 
     # ------------------------------------------------------------------ Ultralytics-shaped API

@@ -184,6 +184,21 @@ int obb_conv_dgrad_bf16(obb_ctx *ctx, const uint16_t *dy, const float *w_oihw_ho
                         int32_t cout, int32_t ks, uint16_t *dx, obb_stream_t s);
 int obb_conv_wgrad_bf16(obb_ctx *ctx, const uint16_t *x, const uint16_t *dy, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
                         int32_t ks, float *dw, obb_stream_t s);
+/* Assembled-chain pieces (round 4; Train_OBB.py:796-841 -> loss.backward() under bf16 autocast over fp32 master weights):
+ * obb_conv_pack_bf16: fp32 OIHW master weights ON THE DEVICE -> the bf16 MFMA fragment order of the forward kernel (n_elems from
+ *   obb_conv_packed_elems for the same shape); dgrad_form 1 packs the flipped / channel-transposed weights, so that
+ *   obb_conv_fwd_bf16(dy, packed_dgrad, NULL, ..., cin = cout, cout = cin) IS the input gradient -- no host repack, no synchronisation.
+ * obb_conv_fwd_bf16: y = conv(x) + bias, stride 1, `same` padding, NO activation (the pre-activation is kept for the backward), bf16
+ *   NHWC in / out, fp32 accumulation, one bf16 rounding.
+ * obb_silu_bf16 / obb_silu_bwd_bf16: a = z sigmoid(z);  dz = da * s (1 + z (1 - s)).   obb_bias_grad_bf16: db[c] = sum_pixels dy[pixel][c] (fp32). */
+int obb_conv_packed_elems(obb_ctx *ctx, int32_t cout, int32_t cin, int32_t ks, int32_t H, int32_t W, int32_t dgrad_form, int64_t *n_elems);
+int obb_conv_pack_bf16(obb_ctx *ctx, const float *w_oihw, int32_t cout, int32_t cin, int32_t ks, int32_t H, int32_t W, int32_t dgrad_form,
+                       uint16_t *packed, obb_stream_t s);
+int obb_conv_fwd_bf16(obb_ctx *ctx, const uint16_t *x, const uint16_t *packed_w, const float *bias, int32_t B, int32_t H, int32_t W, int32_t cin,
+                      int32_t cout, int32_t ks, uint16_t *y, obb_stream_t s);
+int obb_silu_bf16(obb_ctx *ctx, const uint16_t *z, uint16_t *a, int64_t n, obb_stream_t s);
+int obb_silu_bwd_bf16(obb_ctx *ctx, const uint16_t *z, const uint16_t *da, uint16_t *dz, int64_t n, obb_stream_t s);
+int obb_bias_grad_bf16(obb_ctx *ctx, const uint16_t *dy, int64_t npix, int32_t cout, float *db, obb_stream_t s);
 
 /* ------------------------------------------------------------------ S1: model(...) -> results[0].obb  (Detect_OBB.py:26,81-83,228-231) */
 /* Weight blob ("OBBW" format, produced by the Python side from BN-folded conv weights) for a

@@ -41,6 +41,12 @@ SIGNATURES = {
     "obb_rotated_tal_assign": [_V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _V, _V, _V, _V, _V, _V],
     "obb_conv_dgrad_bf16": [_V, _V, c_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
     "obb_conv_wgrad_bf16": [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
+    "obb_conv_packed_elems": [_V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)],
+    "obb_conv_pack_bf16": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
+    "obb_conv_fwd_bf16": [_V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V],
+    "obb_silu_bf16": [_V, _V, _V, C.c_int64, _V],
+    "obb_silu_bwd_bf16": [_V, _V, _V, _V, C.c_int64, _V],
+    "obb_bias_grad_bf16": [_V, _V, C.c_int64, C.c_int32, _V, _V],
     "obb_gather_tiles": [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, C.c_int32, C.c_int32, _V, _V],
     "obb_letterbox": [_V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V,
                       C.c_int32, C.c_int32, _V],

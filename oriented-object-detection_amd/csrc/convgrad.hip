@@ -99,6 +99,69 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     if (co < cout && ci < cin) dw[((size_t)co * cin + ci) * taps + t] = s;
 }
 
+// ---- assembled-chain pieces (round 4): device-side weight packing (no per-call host repack / synchronisation), the training forward that keeps
+//      the pre-activation, SiLU forward / backward, bias gradient
+// bf16 round-to-nearest-even of an fp32 value (host_to_bf16's bit arithmetic)
+__device__ __forceinline__ unsigned short dev_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float dev_from_bf16(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// fp32 OIHW master weights (device) -> the forward kernel's bf16 A-operand fragment order [cout block][stage][k step][fragment][lane][8]
+// (pack_conv_weights' index arithmetic, element for element).  tflip = 1: the dgrad form -- the logical conv has the channel roles swapped and
+// the taps flipped: W'[ci][co][t] = W[co][ci][taps - 1 - t].
+__global__ __launch_bounds__(256) void k_pack_conv_bf16(const float *__restrict__ w, int coutL, int cinL, int ks, int CK, int NF, int tflip, unsigned short *__restrict__ out,
+                                                       int64_t total) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int cpk = CK / 8, taps = ks * ks, kst = ((ks == 3 ? 9 : 1) * cpk + 3) / 4, nstage = (cinL + CK - 1) / CK;
+    const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
+    int64_t rest = o >> 9;
+    const int f = (int)(rest % NF); rest /= NF;
+    const int k = (int)(rest % kst); rest /= kst;
+    const int st = (int)(rest % nstage);
+    const int cb = (int)(rest / nstage);
+    const int r = lane & 15, gq = lane >> 4;
+    const int co = cb * 16 * NF + (r >> 2) * 4 * NF + f * 4 + (r & 3);
+    const int q = k * 4 + gq;
+    const int tap = ks == 3 ? q / cpk : 0, c0 = ks == 3 ? (q % cpk) * 8 : q * 8;
+    const int c = st * CK + c0 + j;
+    float v = 0.f;
+    if (co < coutL && c < cinL && tap < taps && (ks == 3 || c0 < CK))
+        v = tflip ? w[((size_t)c * coutL + co) * taps + (taps - 1 - tap)] : w[((size_t)co * cinL + c) * taps + tap];
+    out[o] = dev_to_bf16(v);
+}
+
+__global__ __launch_bounds__(256) void k_silu_bf16(const unsigned short *__restrict__ z, unsigned short *__restrict__ a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = dev_from_bf16(z[i]);
+    a[i] = dev_to_bf16(x / (1.0f + expf(-x)));
+}
+
+// dz = da * silu'(z), silu'(z) = s (1 + z (1 - s)), s = sigmoid(z): what autograd computes for x * sigmoid(x); bf16 in / out, fp32 inside
+__global__ __launch_bounds__(256) void k_silu_bwd_bf16(const unsigned short *__restrict__ z, const unsigned short *__restrict__ da, unsigned short *__restrict__ dz, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = dev_from_bf16(z[i]), g = dev_from_bf16(da[i]);
+    const float sg = 1.0f / (1.0f + expf(-x));
+    dz[i] = dev_to_bf16(g * (sg * (1.0f + x * (1.0f - sg))));
+}
+
+// db[c] = sum over the pixels of dy[pixel][c]: a workgroup per 64-channel column block, fp32 partial sums per thread row, fixed-order tree
+__global__ __launch_bounds__(256) void k_bias_grad_bf16(const unsigned short *__restrict__ dy, int64_t npix, int cout, float *__restrict__ db) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rowg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cout)
+        for (int64_t p = rowg; p < npix; p += 4) s += dev_from_bf16(dy[p * cout + c]);
+    part[rowg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rowg == 0 && c < cout) db[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 }  // namespace obb
 
 using namespace obb;
@@ -124,7 +187,7 @@ int obb_conv_dgrad_bf16(obb_ctx *ctx, const uint16_t *dy, const float *w_oihw_ho
     // [packed weights][zero bias][2 KiB: the forward kernel's `lut` argument -- unused as a table here (no uint8 input), but lanes without an
     //  output pixel store into lut + 512 B .. + 1.5 KiB (conv.hip EXACT: every store unconditional), so it must be real memory]
     const size_t woff = (wbytes + 255) & ~(size_t)255, boff = (bbytes + 255) & ~(size_t)255;
-    char *ws = (char *)ctx->workspace(WS_GEOM_A, woff + boff + 2048);
+    char *ws = (char *)ctx->workspace(WS_TRAIN_B, woff + boff + 2048);
     if (!ws) return set_error(ctx, OBB_ERR_HIP, "obb_conv_dgrad_bf16: workspace allocation failed");
     float *bias = (float *)(ws + woff);
     const bf16_t *sink = (const bf16_t *)(ws + woff + boff);
@@ -165,12 +228,92 @@ int obb_conv_wgrad_bf16(obb_ctx *ctx, const uint16_t *x, const uint16_t *dy, int
     const int ntiles = B * ((H + R - 1) / R);
     int nwalk = std::max(1, std::min(ntiles, 512 / (ncob * ncib)));
     const size_t per = (size_t)ncob * ncib * taps * 4096;
-    float *slabs = (float *)ctx->workspace(WS_GEOM_B, (size_t)nwalk * per * 4);
+    float *slabs = (float *)ctx->workspace(WS_TRAIN_C, (size_t)nwalk * per * 4);
     if (!slabs) return set_error(ctx, OBB_ERR_HIP, "obb_conv_wgrad_bf16: workspace allocation failed");
     const dim3 grid((unsigned)nwalk, (unsigned)ncob, (unsigned)ncib);
     if (ks == 3) hipLaunchKernelGGL((k_conv_wgrad<3>), grid, dim3(256), lds, st, x, dy, (int)B, (int)H, (int)W, (int)cin, (int)cout, R, slabs);
     else hipLaunchKernelGGL((k_conv_wgrad<1>), grid, dim3(256), lds, st, x, dy, (int)B, (int)H, (int)W, (int)cin, (int)cout, R, slabs);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((int64_t)per, 256)), dim3(256), 0, st, slabs, nwalk, ncob, ncib, taps, (int)cin, (int)cout, dw);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_conv_packed_elems(obb_ctx *ctx, int32_t cout, int32_t cin, int32_t ks, int32_t H, int32_t W, int32_t dgrad_form, int64_t *n_elems) {
+    OBB_REQUIRE(ctx, ctx && n_elems && cout > 0 && cin > 0 && (ks == 1 || ks == 3) && H > 0 && W > 0, "obb_conv_packed_elems: bad arguments");
+    const int coutL = dgrad_form ? cin : cout, cinL = dgrad_form ? cout : cin;
+    const ConvTiling t = plan_conv(ks, 1, cinL, coutL, H, W, false);
+    const int nstage = (cinL + t.CK - 1) / t.CK, ncb = (coutL + 16 * t.NF - 1) / (16 * t.NF);
+    *n_elems = (int64_t)ncb * nstage * conv_ksteps(ks, t.CK) * t.NF * 64 * 8;
+    return OBB_OK;
+}
+
+int obb_conv_pack_bf16(obb_ctx *ctx, const float *w_oihw, int32_t cout, int32_t cin, int32_t ks, int32_t H, int32_t W, int32_t dgrad_form, uint16_t *packed,
+                       obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && w_oihw && packed, "obb_conv_pack_bf16: NULL buffer");
+    int64_t n = 0;
+    int rc = obb_conv_packed_elems(ctx, cout, cin, ks, H, W, dgrad_form, &n);
+    if (rc) return rc;
+    const int coutL = dgrad_form ? cin : cout, cinL = dgrad_form ? cout : cin;
+    const ConvTiling t = plan_conv(ks, 1, cinL, coutL, H, W, false);
+    hipLaunchKernelGGL(k_pack_conv_bf16, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, w_oihw, coutL, cinL, (int)ks, t.CK, t.NF, dgrad_form ? 1 : 0, packed, n);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_conv_fwd_bf16(obb_ctx *ctx, const uint16_t *x, const uint16_t *packed_w, const float *bias, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                      int32_t ks, uint16_t *y, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && B >= 0 && H > 0 && W > 0 && (ks == 1 || ks == 3), "obb_conv_fwd_bf16: bad arguments");
+    OBB_REQUIRE(ctx, cin % 8 == 0 && cout % 8 == 0 && cin >= 8 && cout >= 8, "obb_conv_fwd_bf16: channel counts must be multiples of 8");
+    if (B == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, x && packed_w && y, "obb_conv_fwd_bf16: NULL buffer");
+    hipStream_t st = (hipStream_t)s;
+    const ConvTiling t = plan_conv(ks, 1, cin, cout, H, W, false);
+    // [bias padded to the kernel's 64-float granule (zeros without one)][2 KiB: the `lut` argument = the sink of the kernel's unconditional stores]
+    const size_t bbytes = (((size_t)cout + 63) / 64 * 64 * 4 + 256 + 255) & ~(size_t)255;
+    char *ws = (char *)ctx->workspace(WS_TRAIN_A, bbytes + 2048);
+    if (!ws) return set_error(ctx, OBB_ERR_HIP, "obb_conv_fwd_bf16: workspace allocation failed");
+    OBB_HIP(ctx, hipMemsetAsync(ws, 0, bbytes, st));
+    if (bias) OBB_HIP(ctx, hipMemcpyAsync(ws, bias, (size_t)cout * 4, hipMemcpyDeviceToDevice, st));
+    ConvLaunch L;
+    L.in.p = (void *)x; L.in.bs = (int64_t)H * W * cin; L.in.cs = cin; L.in.co = 0;
+    L.out.p = (void *)y; L.out.bs = (int64_t)H * W * cout; L.out.cs = cout; L.out.co = 0;
+    L.wpk = (const bf16_t *)packed_w; L.bias = (const float *)ws; L.lut = (const bf16_t *)(ws + bbytes);
+    L.B = B; L.Hin = L.Hout = H; L.Win = L.Wout = W; L.cin = cin; L.cout = cout; L.ks = ks; L.stride = 1; L.act = 0; L.f16 = 0;
+    L.TH = t.TH; L.TW = t.TW; L.MF = t.MF; L.NF = t.NF; L.CK = t.CK;
+    L.tiles_y = (H + t.TH - 1) / t.TH; L.tiles_x = (W + t.TW - 1) / t.TW;
+    if (ks == 1) {
+        const int64_t npx = (int64_t)B * H * W;
+        OBB_REQUIRE(ctx, npx < (1ll << 31) / 4, "obb_conv_fwd_bf16: too many pixels for one launch");
+        L.B = 1; L.Hin = L.Hout = 1; L.Win = L.Wout = (int)npx;
+        L.tiles_y = 1; L.tiles_x = (int)((npx + L.TW - 1) / L.TW);
+    }
+    hipError_t e = launch_conv(L, st);
+    if (e != hipSuccess) return set_error(ctx, OBB_ERR_HIP, "obb_conv_fwd_bf16: launch failed: %s", hipGetErrorString(e));
+    return OBB_OK;
+}
+
+int obb_silu_bf16(obb_ctx *ctx, const uint16_t *z, uint16_t *a, int64_t n, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_silu_bf16: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, z && a, "obb_silu_bf16: NULL buffer");
+    hipLaunchKernelGGL(k_silu_bf16, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, z, a, n);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_silu_bwd_bf16(obb_ctx *ctx, const uint16_t *z, const uint16_t *da, uint16_t *dz, int64_t n, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && n >= 0, "obb_silu_bwd_bf16: bad arguments");
+    if (n == 0) return OBB_OK;
+    OBB_REQUIRE(ctx, z && da && dz, "obb_silu_bwd_bf16: NULL buffer");
+    hipLaunchKernelGGL(k_silu_bwd_bf16, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, z, da, dz, n);
+    OBB_LAUNCH_CHECK(ctx);
+    return OBB_OK;
+}
+
+int obb_bias_grad_bf16(obb_ctx *ctx, const uint16_t *dy, int64_t npix, int32_t cout, float *db, obb_stream_t s) {
+    OBB_REQUIRE(ctx, ctx && npix >= 1 && cout >= 1, "obb_bias_grad_bf16: bad arguments");
+    OBB_REQUIRE(ctx, dy && db, "obb_bias_grad_bf16: NULL buffer");
+    hipLaunchKernelGGL(k_bias_grad_bf16, dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, (hipStream_t)s, dy, npix, (int)cout, db);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;
 }

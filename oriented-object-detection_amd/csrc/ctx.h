@@ -60,7 +60,7 @@ extern thread_local std::string g_tls_error;
 #define OBB_LAUNCH_CHECK(ctx) OBB_HIP(ctx, hipGetLastError())
 
 // workspace slots
-enum { WS_GEOM_A = 0, WS_GEOM_B, WS_GEOM_C, WS_GEOM_D, WS_GEOM_E, WS_NMS_A, WS_NMS_B, WS_NMS_C, WS_NMS_D, WS_SURV_A, WS_SURV_B, WS_SEL, WS_DT, WS_COUNT };
+enum { WS_GEOM_A = 0, WS_GEOM_B, WS_GEOM_C, WS_GEOM_D, WS_GEOM_E, WS_NMS_A, WS_NMS_B, WS_NMS_C, WS_NMS_D, WS_SURV_A, WS_SURV_B, WS_SEL, WS_DT, WS_TRAIN_A, WS_TRAIN_B, WS_TRAIN_C, WS_COUNT };  // (WS_TRAIN_*: the training kernels' own scratch -- never shared with the inference path's slots)
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 }  // namespace obb

@@ -432,6 +432,51 @@ def conv_wgrad_bf16(x, dy, ks):
     return dw
 
 
+def conv_pack_bf16(w, H, W, dgrad_form=False):
+    """fp32 OIHW master weights (device) -> the bf16 MFMA fragment order of the conv kernel for H x W maps, packed ON THE DEVICE (no host
+    repack, no synchronisation); dgrad_form: the flipped / channel-transposed weights whose forward convolution is the input gradient."""
+    ww = _chk(w, torch.float32, "w")
+    cout, cin, ks, _ = ww.shape
+    n = C.c_int64(0)
+    _call("obb_conv_packed_elems", ctx(ww.device), cout, cin, ks, int(H), int(W), int(bool(dgrad_form)), C.byref(n))
+    out = torch.empty(n.value, dtype=torch.bfloat16, device=ww.device)
+    _call("obb_conv_pack_bf16", ctx(ww.device), _p(ww), cout, cin, ks, int(H), int(W), int(bool(dgrad_form)), _p(out), _stream())
+    return out
+
+
+def conv_fwd_bf16(x, packed, bias, cout, ks):
+    """y = conv(x) + bias (stride 1, `same` padding, no activation): x bf16 [B,H,W,cin] NHWC, packed = conv_pack_bf16 of the [cout,cin,ks,ks]
+    weights for this H x W, bias fp32 [cout] or None -> bf16 [B,H,W,cout]."""
+    xx = _chk(x, torch.bfloat16, "x")
+    B, H, W, cin = xx.shape
+    y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=xx.device)
+    b = _chk(bias, torch.float32, "bias") if bias is not None else None
+    _call("obb_conv_fwd_bf16", ctx(xx.device), _p(xx), _p(_chk(packed, torch.bfloat16, "packed")), _p(b), B, H, W, cin, int(cout), int(ks), _p(y), _stream())
+    return y
+
+
+def silu_bf16(z):
+    zz = _chk(z, torch.bfloat16, "z")
+    a = torch.empty_like(zz)
+    _call("obb_silu_bf16", ctx(zz.device), _p(zz), _p(a), zz.numel(), _stream())
+    return a
+
+
+def silu_bwd_bf16(z, da):
+    zz, d = _chk(z, torch.bfloat16, "z"), _chk(da, torch.bfloat16, "da")
+    dz = torch.empty_like(zz)
+    _call("obb_silu_bwd_bf16", ctx(zz.device), _p(zz), _p(d), _p(dz), zz.numel(), _stream())
+    return dz
+
+
+def bias_grad_bf16(dy, out=None):
+    d = _chk(dy, torch.bfloat16, "dy")
+    cout = d.shape[-1]
+    db = out if out is not None else torch.empty(cout, dtype=torch.float32, device=d.device)
+    _call("obb_bias_grad_bf16", ctx(d.device), _p(d), d.numel() // cout, cout, _p(_chk(db, torch.float32, "db")), _stream())
+    return db
+
+
 def tile_survivors(det, count, lb, tile_ids, rects, margin, iou_thr, strike_cls=1):
     """det float32[B, max_det, 7] + count int32[B] (decode_nms) -> (records int32[B * max_det, 12] (capacity), tile_off int32[B + 1],
     n_records int32[1]), all on the device: result construction, per-detection body (border filter `margin`), per-tile merge at `iou_thr`

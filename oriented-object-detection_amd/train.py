@@ -103,3 +103,51 @@ def allreduce_gradients(flat_grads, group=None, bucket_mb=25.0, average=True):
         for g in flat_grads:
             g.mul_(1.0 / world)
     return len(works)
+
+
+class BoxBranchStep:
+    """ONE assembled training step of the box branch of a head level (ultralytics Detect.cv2[i]: Conv 3x3 + SiLU, Conv 3x3 + SiLU, Conv2d 1x1
+    -> 4 x 16 DFL logits per anchor; BatchNorm folded as in the OBBW blob) under the DFL term of the OBB loss -- what `loss.backward()` +
+    `optimizer.step()` do to these three layers inside `model.train(...)` (Train_OBB.py:796-841; bf16 autocast over fp32 master weights):
+        pack (device) -> conv -> SiLU -> conv -> SiLU -> conv -> DFL loss + gradient -> [wgrad, bias grad, dgrad, SiLU'] x 3 -> optimiser.
+    Every arithmetic step is a kernel of libobbhip; the master weights live in two flat optimiser groups (weights with decay, biases
+    without), the gradients are written straight into the groups' flat gradient buffers.  Activations and gradients between layers are bf16
+    (one rounding per tensor), sums fp32."""
+
+    def __init__(self, weights, biases, H, W, optimizer="SGD", lr=0.01, momentum=0.9, weight_decay=5e-4):
+        dev = weights[0].device
+        self.H, self.W = H, W
+        self.wshapes = [tuple(w.shape) for w in weights]
+        self.bshapes = [tuple(b.shape) for b in biases]
+        self.opt_w = FlatOptimizer(sum(int(math.prod(s)) for s in self.wshapes), dev, optimizer, lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.opt_b = FlatOptimizer(sum(int(math.prod(s)) for s in self.bshapes), dev, optimizer, lr=lr, momentum=momentum, weight_decay=0.0)
+        self.w, self.dw = FlatOptimizer.views(self.opt_w.param, self.wshapes), FlatOptimizer.views(self.opt_w.grad, self.wshapes)
+        self.b, self.db = FlatOptimizer.views(self.opt_b.param, self.bshapes), FlatOptimizer.views(self.opt_b.grad, self.bshapes)
+        for dst, src in zip(self.w + self.b, list(weights) + list(biases)):
+            dst.copy_(src)
+
+    def forward_backward(self, x, target_ltrb, weight=None, target_scores_sum=1.0):
+        """x bf16 [B,H,W,cin]; target_ltrb fp32 [B*H*W, 4] (bins), weight fp32 [B*H*W] or None -> (loss fp32[1], dx bf16 like x); the weight
+        and bias gradients are left in the optimiser groups' gradient buffers (self.dw, self.db)."""
+        H, W = self.H, self.W
+        ks = [s[2] for s in self.wshapes]
+        fw = [ops.conv_pack_bf16(w, H, W) for w in self.w]                       # this step's bf16 weights, forward order
+        z1 = ops.conv_fwd_bf16(x, fw[0], self.b[0], self.wshapes[0][0], ks[0]); a1 = ops.silu_bf16(z1)
+        z2 = ops.conv_fwd_bf16(a1, fw[1], self.b[1], self.wshapes[1][0], ks[1]); a2 = ops.silu_bf16(z2)
+        out = ops.conv_fwd_bf16(a2, fw[2], self.b[2], self.wshapes[2][0], ks[2])
+        loss, g = ops.dfl_loss(out.float().reshape(-1, self.wshapes[2][0]), target_ltrb, weight, target_scores_sum)
+        d3 = g.reshape(out.shape).to(torch.bfloat16)
+        bw = [ops.conv_pack_bf16(w, H, W, dgrad_form=True) for w in self.w]     # flipped / transposed: the input-gradient convolutions
+        self.dw[2].copy_(ops.conv_wgrad_bf16(a2, d3, ks[2])); ops.bias_grad_bf16(d3, self.db[2])
+        d2 = ops.silu_bwd_bf16(z2, ops.conv_fwd_bf16(d3, bw[2], None, self.wshapes[2][1], ks[2]))
+        self.dw[1].copy_(ops.conv_wgrad_bf16(a1, d2, ks[1])); ops.bias_grad_bf16(d2, self.db[1])
+        d1 = ops.silu_bwd_bf16(z1, ops.conv_fwd_bf16(d2, bw[1], None, self.wshapes[1][1], ks[1]))
+        self.dw[0].copy_(ops.conv_wgrad_bf16(x, d1, ks[0])); ops.bias_grad_bf16(d1, self.db[0])
+        dx = ops.conv_fwd_bf16(d1, bw[0], None, self.wshapes[0][1], ks[0])
+        return loss, dx
+
+    def step(self, x, target_ltrb, weight=None, target_scores_sum=1.0, group=None):
+        loss, dx = self.forward_backward(x, target_ltrb, weight, target_scores_sum)
+        allreduce_gradients([self.opt_w.grad, self.opt_b.grad], group)           # DDP: the gradient average (no-op on one rank)
+        self.opt_w.step(); self.opt_b.step()
+        return loss, dx

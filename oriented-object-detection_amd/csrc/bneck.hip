@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void k_bneck_stripe(const BneckParams P) {
 
 // ------------------------------------------------------------------------------------------------ host side
 
-bool bneck_supported(int C, int H, int W) { return ((C == 16 && W == 104) || (C == 32 && W == 52)) && H > 0 && H % kBnRows == 0; }
+// (W = 104 / 52: the 416-px tile's levels; W = 32 / 16: the same blocks of a 128-px tile -- the dual-scale default of Detect_OBB.py:24-28)
+bool bneck_supported(int C, int H, int W) { return ((C == 16 && (W == 104 || W == 32)) || (C == 32 && (W == 52 || W == 16))) && H > 0 && H % kBnRows == 0; }
 
 bool bneck_cv2_supported(int C, int CO) { return (C == 16 && CO == 64) || (C == 32 && (CO == 64 || CO == 128)); }
 
@@ -327,10 +328,16 @@ hipError_t launch_bneck(const BneckLaunch &L, hipStream_t st) {
     int64_t spw = ns / (256 * 3 * 2);
     P.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, spw_max));
     dim3 grid((unsigned)((ns + P.spw - 1) / P.spw));
-    if (L.C == 16) return L.CO ? launch_t<16, 104, 64>(L, P, grid, st) : launch_t<16, 104, 0>(L, P, grid, st);
-    if (L.CO == 128) return launch_t<32, 52, 128>(L, P, grid, st);
-    if (L.CO == 64) return launch_t<32, 52, 64>(L, P, grid, st);
-    return launch_t<32, 52, 0>(L, P, grid, st);
+    if (L.C == 16 && L.W == 104) return L.CO ? launch_t<16, 104, 64>(L, P, grid, st) : launch_t<16, 104, 0>(L, P, grid, st);
+    if (L.C == 16) return L.CO ? launch_t<16, 32, 64>(L, P, grid, st) : launch_t<16, 32, 0>(L, P, grid, st);
+    if (L.W == 52) {
+        if (L.CO == 128) return launch_t<32, 52, 128>(L, P, grid, st);
+        if (L.CO == 64) return launch_t<32, 52, 64>(L, P, grid, st);
+        return launch_t<32, 52, 0>(L, P, grid, st);
+    }
+    if (L.CO == 128) return launch_t<32, 16, 128>(L, P, grid, st);
+    if (L.CO == 64) return launch_t<32, 16, 64>(L, P, grid, st);
+    return launch_t<32, 16, 0>(L, P, grid, st);
 }
 
 }  // namespace obb

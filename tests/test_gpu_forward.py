@@ -294,11 +294,12 @@ def test_c3k_image_kernel(ops, net_n):
         assert float(d.mean()) < (1e-3 if net_n.prec == "f16" else 1e-2) and float(d.max()) < (0.05 if net_n.prec == "f16" else 0.4)
 
 
-def test_fused_bottleneck_stripes(ops, net_n):
-    """Bottleneck(3x3, 3x3, shortcut) of the 104 / 52 levels as one stripe kernel: same rounding points as the two separate convs.
-    The 16 -> 8 -> 16 block also sums in the same order (bit-identical); the 32 -> 16 -> 32 block sums all 32 input channels in one
-    k loop where the separate kernel uses two channel stages: rare 1-ulp flips of 16-bit values."""
-    B, h, w = 3, 416, 416
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 9)])
+def test_fused_bottleneck_stripes(ops, net_n, h, w, B):
+    """Bottleneck(3x3, 3x3, shortcut) of the 104 / 52 levels (416-px tiles) and of the 32 / 16 levels (128-px tiles: the dual-scale default) as
+    one stripe kernel: same rounding points as the two separate convs.  The 16 -> 8 -> 16 block also sums in the same order (bit-identical);
+    the 32 -> 16 -> 32 block sums all 32 input channels in one k loop where the separate kernel uses two channel stages: rare 1-ulp flips of
+    16-bit values."""
     x = torch.as_tensor(_tiles(91, B, h, w)).cuda()
     ref = {}
     ops.model_load(net_n.to_blob(), precision=net_n.prec, tail=False)
@@ -322,14 +323,15 @@ def test_fused_bottleneck_stripes(ops, net_n):
         else:
             assert float((d / ref[name].abs().clamp_min(1.0)).max()) <= 4 * ulp and float((d > 0).float().mean()) < 0.05
     dh = (head[..., :77] - head_ref[..., :77]).abs()
-    assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), float(dh.mean())
+    # (128-px tiles: the same 1-ulp flips reach a head of 336 anchors through 4 x 4 / 8 x 8 maps -- measured 4.7e-3 for fp16)
+    assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2) * (1 if h == 416 else 2.5), float(dh.mean())
 
 
-def test_closing_1x1_behind_the_bottleneck(ops, net_n):
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 9)])
+def test_closing_1x1_behind_the_bottleneck(ops, net_n, h, w, B):
     """C3k2 blocks 2, 4 and 16: cv2 over [y0 | y1 | y2] runs on every 16-pixel fragment right behind the Bottleneck's second conv
     (y0 from global memory, y1 from the LDS image, y2 from the producing lane's registers).  Same 16-bit rounding of y2; the k sum is
     split differently from the stand-alone 1x1 (and uses a 16-wide MFMA step for the 16-channel block): 1-ulp flips of 16-bit outputs."""
-    B, h, w = 3, 416, 416
     x = torch.as_tensor(_tiles(37, B, h, w)).cuda()
     names = ("model.2.cv2", "model.4.cv2", "model.16.cv2")
     ops.model_load(net_n.to_blob(), precision=net_n.prec, bneck_cv2=False)
@@ -353,7 +355,8 @@ def test_closing_1x1_behind_the_bottleneck(ops, net_n):
             # (model.4 sees model.2's few flipped inputs on top of its own)
             assert float((d / ref[n].abs().clamp_min(1.0)).max()) <= 4 * ulp and float((d > 0).float().mean()) < (0.01 if n == "model.2.cv2" else 0.15)
     dh = (head[..., :77] - head_ref[..., :77]).abs()
-    assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2), float(dh.mean())
+    # (128-px tiles: measured 5.4e-3 for fp16 -- see test_fused_bottleneck_stripes)
+    assert float(dh.mean()) < (3e-3 if net_n.prec == "f16" else 3e-2) * (1 if h == 416 else 2.5), float(dh.mean())
 
 
 @pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 5), (416, 288, 1), (192, 416, 2)])

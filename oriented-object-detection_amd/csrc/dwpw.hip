@@ -175,12 +175,14 @@ __global__ __launch_bounds__(256, 2) void k_dwpw_stripe(const DwPwParams P) {
 
 static int dwpw_rows(int W) {
     static const int r52 = getenv("OBB_DWPW_R52") ? atoi(getenv("OBB_DWPW_R52")) : 2;  // measured: 2-row stripes (41 KB of LDS, three groups per CU) 99.6 k vs 4-row 98.9 k tiles/s
+    if (W == 16) return 4;  // (128-px tiles: 64 pixels = one fragment per wave)
+    if (W == 8) return 8;   // (the whole 8 x 8 map)
     return W == 52 ? (r52 == 4 ? 4 : 2) : 2;
 }
 
 bool dwpw_supported(int cin, int cout, int H, int W, int tail_cout) {
     if (cout != 64 || tail_cout < 0 || tail_cout > 16) return false;
-    const bool shape = (cin == 64 && W == 52) || ((cin == 64 || cin == 128) && W == 26);
+    const bool shape = (cin == 64 && (W == 52 || W == 16)) || ((cin == 64 || cin == 128) && (W == 26 || W == 8));  // 416-px levels; 128-px levels (Detect_OBB.py:24-28)
     if (!shape || H <= 0 || H % dwpw_rows(W)) return false;
     return tail_cout == 0 || (cin == 64 && tail_cout % 4 == 0);  // the branch's second pair (64 -> 64 -> nc) carries the tail (whole float4s per lane)
 }
@@ -231,6 +233,9 @@ hipError_t launch_dwpw(const DwPwLaunch &L, hipStream_t st) {
     int64_t spw = ns / (256 * 3 * 2);
     P.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, spw_max));
     dim3 grid((unsigned)((ns + P.spw - 1) / P.spw));
+    if (L.W == 16) return L.tail_cout ? launch_t<64, 16, 4, true>(L, P, grid, st) : launch_t<64, 16, 4, false>(L, P, grid, st);
+    if (L.W == 8 && L.cin == 128) return launch_t<128, 8, 8, false>(L, P, grid, st);
+    if (L.W == 8) return L.tail_cout ? launch_t<64, 8, 8, true>(L, P, grid, st) : launch_t<64, 8, 8, false>(L, P, grid, st);
     if (L.W == 52 && R == 2) return L.tail_cout ? launch_t<64, 52, 2, true>(L, P, grid, st) : launch_t<64, 52, 2, false>(L, P, grid, st);
     if (L.W == 52) return L.tail_cout ? launch_t<64, 52, 4, true>(L, P, grid, st) : launch_t<64, 52, 4, false>(L, P, grid, st);
     if (L.cin == 128) return launch_t<128, 26, 2, false>(L, P, grid, st);

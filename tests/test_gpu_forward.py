@@ -251,11 +251,12 @@ def test_cv1_behind_stride2_conv(ops, net_n, h, w, B):
     assert torch.equal(head[..., :77], ref_head[..., :77])
 
 
-def test_depthwise_pointwise_stripes(ops, net_n):
-    """Class branch of the head at the 52 / 26 levels: DWConv 3x3 -> Conv 1x1 (-> plain 1x1 into the head tensor) as one stripe kernel
-    per pair, the depthwise result living only in registers as the MFMA operand.  Same arithmetic and rounding points as the separate
-    kernels for the first pair (identical activations); the trailing 1x1 sums its 64 inputs in a different k order (fp32: ~1e-6)."""
-    B, h, w = 3, 416, 416
+@pytest.mark.parametrize("h,w,B", [(416, 416, 3), (128, 128, 9)])
+def test_depthwise_pointwise_stripes(ops, net_n, h, w, B):
+    """Class branch of the head at the 52 / 26 levels (416-px tiles) and the 16 / 8 levels (128-px tiles): DWConv 3x3 -> Conv 1x1 (-> plain 1x1
+    into the head tensor) as one stripe kernel per pair, the depthwise result living only in registers as the MFMA operand.  Same arithmetic
+    and rounding points as the separate kernels for the first pair (identical activations); the trailing 1x1 sums its 64 inputs in a
+    different k order (fp32: ~1e-6)."""
     x = torch.as_tensor(_tiles(71, B, h, w)).cuda()
     names = ("model.23.cv3.0.0.1", "model.23.cv3.1.0.1")
     ops.model_load(net_n.to_blob(), precision=net_n.prec, dwpw=False)

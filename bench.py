@@ -289,7 +289,7 @@ def main():
         tiles, see tools/profile_all.sh), scaled to `nt` tiles; (None, None) if no profile of that arithmetic is there."""
         import re
         stem = "forward_f32_hbm_traffic_b256.txt" if precision == "f32" else "forward_hbm_traffic_b256.txt"
-        for rnd in ("r03_", "r02_", "r01_"):
+        for rnd in ("r04_", "r03_", "r02_", "r01_"):
             try:
                 m = re.search(r"-> ([0-9.]+) MB / tile", open(os.path.join(ROOT, "profiles", rnd + stem)).read(600))
                 if m:

@@ -2,7 +2,7 @@
 # Then: python tools/install_profiles.py gpurun_out/final   (copies / condenses them into profiles/r03_*)
 # The headline arithmetic is fp32 (bench.py default); the f16 fast mode is profiled beside it.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/final; mkdir -p $O
+O=${OUT:-gpurun_out/final}; mkdir -p $O
 LP="python3 tools/layer_profile.py"
 # parts (a gpurun call is capped at 1200 s): a = benches + kernel traces, b = f32 counters, c = f16 counters + post-processing
 if [ "${PART:-a}" = a ]; then

@@ -894,12 +894,16 @@ __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__rest
 
 // ------------------------------------------------------------------------------------------------ consensus (single workgroup)
 
+struct ConsOff { int64_t v[17]; };  // scale k owns rows [v[k], v[k + 1]): passed BY VALUE (a host array copied to the device per call would be a
+                                    // pageable host-to-device copy inside the entry point -- host-side latency, and host memory referenced by a captured graph)
+
 __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
-                                                  const double *__restrict__ conf, const int64_t *__restrict__ off,
+                                                  const double *__restrict__ conf, const ConsOff offs,
                                                   int32_t nscales, double iou_partner, double cons_low, double cons_high,
                                                   uint8_t *__restrict__ state /* [total]: bit0 alive, bit1 visited */,
                                                   BoxMeta *__restrict__ meta, int32_t *__restrict__ out_idx,
                                                   int32_t *__restrict__ n_out, const int32_t *__restrict__ only_if /* nullptr, or run only when *only_if != 0 */) {
+    const int64_t *off = offs.v;
     if (only_if && *only_if == 0) return;
     __shared__ double r_conf[256], r_iou[256];
     __shared__ int32_t r_idx[256];
@@ -989,9 +993,10 @@ __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ bo
 // overflows, the single-workgroup walk (k_consensus) runs instead.
 static constexpr int kConsK = 32;
 
-__global__ __launch_bounds__(256) void k_cons_prep(const double *__restrict__ boxes, const double *__restrict__ conf, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(256) void k_cons_prep(const double *__restrict__ boxes, const double *__restrict__ conf, const ConsOff offs,
                                                   int32_t nscales, double cons_low, uint8_t *__restrict__ state, uint8_t *__restrict__ scale_id,
                                                   BoxMeta *__restrict__ meta, int32_t *__restrict__ deg, int32_t *__restrict__ flags) {
+    const int64_t *off = offs.v;
     const int64_t total = off[nscales];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { flags[0] = 0; flags[1] = 0; }
@@ -1595,13 +1600,13 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
     for (int k = 0; k < nscales; ++k) OBB_REQUIRE(ctx, off_host[k] <= off_host[k + 1], "obb_consensus: offsets must ascend");
     if (total == 0) { OBB_HIP(ctx, hipMemsetAsync(n_out, 0, sizeof(int32_t), st)); return OBB_OK; }
     OBB_REQUIRE(ctx, boxes && cls && conf && out_idx, "obb_consensus: NULL buffer");
-    int64_t *off = (int64_t *)ctx->workspace(WS_GEOM_D, 256);
+    ConsOff off;
+    for (int k = 0; k <= 16; ++k) off.v[k] = off_host[std::min<int>(k, nscales)];
     uint8_t *state = (uint8_t *)ctx->workspace(WS_GEOM_C, (size_t)total * 2 + 256);
     BoxMeta *meta = (BoxMeta *)ctx->workspace(WS_NMS_A, sizeof(BoxMeta) * (size_t)total);
-    if (!off || !state || !meta) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
-    OBB_HIP(ctx, hipMemcpyAsync(off, off_host, sizeof(int64_t) * (nscales + 1), hipMemcpyHostToDevice, st));
+    if (!state || !meta) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
     if (nscales == 1 || total < 512) {  // passthrough (:357-358), or small enough for the single-workgroup walk
-        hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner,
+        hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, off, nscales, iou_partner,
                            cons_low, cons_high, state, meta, out_idx, n_out, (const int32_t *)nullptr);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
@@ -1613,7 +1618,7 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
     int32_t *ibuf = (int32_t *)ctx->workspace(WS_GEOM_A, sizeof(int32_t) * ((size_t)total * 3 + 64));  // deg | decision | emit | flags
     if (!adj_idx || !adj_iou || !ibuf) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
     int32_t *deg = ibuf, *decision = ibuf + total, *emit = ibuf + 2 * total, *flags = ibuf + 3 * total;
-    hipLaunchKernelGGL(k_cons_prep, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, boxes, conf, (const int64_t *)off, nscales, cons_low, state, scale_id, meta,
+    hipLaunchKernelGGL(k_cons_prep, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, boxes, conf, off, nscales, cons_low, state, scale_id, meta,
                        deg, flags);
     OBB_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_cons_edges, dim3((unsigned)cdiv(total, 256), (unsigned)cdiv(total, 64)), dim3(256), 0, st, boxes, cls, (const uint8_t *)state,
@@ -1623,7 +1628,7 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
                        (const int32_t *)deg, decision, emit, flags, out_idx, n_out);
     OBB_LAUNCH_CHECK(ctx);
     // a detection with more than kConsK candidate partners (flags[0]): the walk itself, on untouched state (it re-derives state and meta)
-    hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, (const int64_t *)off, nscales, iou_partner, cons_low, cons_high, state,
+    hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, off, nscales, iou_partner, cons_low, cons_high, state,
                        meta, out_idx, n_out, (const int32_t *)flags);
     OBB_LAUNCH_CHECK(ctx);
     return OBB_OK;

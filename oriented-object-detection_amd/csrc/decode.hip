@@ -525,14 +525,23 @@ __global__ __launch_bounds__(256) void k_heavy_nms(int A, float iou_thres, int m
             const RBox q = rb[r];
             const uint8_t cq = scls[r];
             bool hit = false;
-            for (int i0 = 0; i0 < r; i0 += 64) {
-                const int i = i0 + lane;
+            // 256 predecessors per step: a lane's four rows are loaded together (four independent global loads in flight -- the loop used to pay
+            // one memory latency per 64 predecessors, ~30 of them in sequence for the last rows of a 2000-candidate tile)
+            for (int i0 = 0; i0 < r; i0 += 256) {
+                RBox p[4];
+                uint8_t cp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u * 64 + lane, r - 1);
+                    p[u] = rb[i]; cp[u] = scls[i];
+                }
                 bool hh = false;
-                if (i < r && !(skip_other_cls && scls[i] != cq)) {
-                    const RBox p = rb[i];
-                    if (!far_apart(p, q, kq)) {
-                        const int dec = bdmax > 0.0f ? probiou_fast_decision(p, q, bdmax) : 0;
-                        hh = dec > 0 || (dec == 0 && probiou(p, q) >= iou_thres);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i < r && !(skip_other_cls && cp[u] != cq) && !far_apart(p[u], q, kq)) {
+                        const int dec = bdmax > 0.0f ? probiou_fast_decision(p[u], q, bdmax) : 0;
+                        hh = hh || dec > 0 || (dec == 0 && probiou(p[u], q) >= iou_thres);
                     }
                 }
                 if (__ballot(hh)) { hit = true; break; }

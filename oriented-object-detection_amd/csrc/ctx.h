@@ -19,7 +19,7 @@ struct Model;  // engine.hip
 // preset from the environment for profiling runs: OBB_GRAPH, OBB_FWD_SPLIT, OBB_MICROBATCH -- read once per context).
 struct EngineOpts {
     bool tail = true, tail16 = true, bneck = true, bneck_cv2 = true, c3kimg = true, dwpw = true, upfold = true, stem = true, front = true, pair = true, hmerge = true,
-         sppf_fuse = true, attn_mfma = true, xtile = true, nitile = true, nc2 = true, blk32 = true, c3k2f = true, graph = true;
+         sppf_fuse = true, attn_mfma = true, xtile = true, nitile = true, nc2 = true, blk32 = true, c3k2f = true, pw32 = true, graph = true;
     int fwd_split = 0 /* auto = 2 chains */, microbatch = 1024;
 };
 }

@@ -21,6 +21,7 @@
 #include "f32path.h"
 #include "front.h"
 #include "nnops.h"
+#include "pw32.h"
 #include "stem.h"
 
 namespace obb {
@@ -48,7 +49,7 @@ struct Buf {
 
 struct Slice { int buf = -1, co = 0, C = 0; };
 
-enum OpType { OP_CONV32, OP_STEM32, OP_C3K2F32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
+enum OpType { OP_CONV32, OP_STEM32, OP_C3K2F32, OP_PW32, OP_CONV, OP_DW, OP_POOL, OP_UP, OP_ATTN, OP_STEM, OP_SPPF, OP_BNECK, OP_C3KIMG, OP_DWPW, OP_FRONT };
 
 struct Op {
     OpType type;
@@ -59,6 +60,7 @@ struct Op {
     ConvLaunch conv;         // OP_CONV
     Conv32Launch c32;        // OP_CONV32 (fp32-arithmetic mode: f32path.hip)
     Stem32Launch stem32;     // OP_STEM32 (fp32 mode: network input layer as row stripes)
+    Pw32Launch pw32;         // OP_PW32 (fp32 mode: 1x1 conv with the activations read straight from global memory into the MFMA operand)
     C3k2F32Launch c3k2f;     // OP_C3K2F32 (fp32 mode: Bottleneck + closing 1x1 of a C3k2 block in one launch)
     StemLaunch stem;         // OP_STEM (network input layer as row stripes)
     FrontLaunch front;       // OP_FRONT (model.0 + model.1 + model.2.cv1 in one launch)
@@ -342,6 +344,24 @@ struct Builder {
         }
         if (M.f32 && ((res.C && P.bufs[res.buf].blk32) || (tail_name && out.buf >= 0 && P.bufs[out.buf].blk32))) {
             err = set_error(ctx, OBB_ERR_STATE, "layer %s: residual / fused-1x1 output in a channel-blocked buffer", name.c_str());
+            return;
+        }
+        if (M.f32 && M.o.pw32 && r->k == 1 && !in_u8 && !op.vin && !tail_name && head_level < 0 && !P.bufs[in.buf].blk32 && pw32_supported(cin, r->c2) &&
+            !(res.C && P.bufs[res.buf].blk32)) {
+            // 1x1 with >= 64 input channels: weights resident in LDS, activations straight from global memory into the MFMA operand (pw32.hip)
+            op.type = OP_PW32;
+            Pw32Launch &L = op.pw32;
+            L.cin = cin; L.cout = r->c2; L.act = r->act;
+            std::vector<float> w2((size_t)r->c2 * cin);
+            for (size_t i = 0; i < w2.size(); ++i) w2[i] = r->w[i];  // (k = 1: OIHW is [cout][cin])
+            L.wpk = upload(pack_pw32_weights(w2.data(), r->c2, cin, perm));
+            std::vector<float> bias32(((size_t)r->c2 + 63) / 64 * 64 + 64, 0.f);
+            for (int c = 0; c < r->c2; ++c) bias32[c] = r->b[perm ? perm[c] : c];
+            L.bias = upload(bias32);
+            op.macs = (double)op.Ho * op.Wo * r->c2 * cin;
+            P.macs_per_img += op.macs;
+            P.ops.push_back(op);
+            P.named[name] = out;
             return;
         }
         if (M.f32) {  // fp32-arithmetic mode: exact-f32 MFMA kernels (f32path.hip)
@@ -1086,6 +1106,13 @@ static int run_forward(obb_ctx *ctx, Plan &P, const uint8_t *tiles, int B, float
                 e = launch_conv32(L, st);
                 break;
             }
+            case OP_PW32: {
+                Pw32Launch L = op.pw32;
+                L.in = tref(P, op.in, boff); L.out = tref(P, op.out, boff); L.res = tref(P, op.res, boff);
+                L.npix = (int64_t)B * op.Ho * op.Wo; L.hw = op.Ho * op.Wo;
+                e = launch_pw32(L, st);
+                break;
+            }
             case OP_C3K2F32: {
                 C3k2F32Launch L = op.c3k2f;
                 L.B = B; L.cat = tref(P, op.in, boff); L.out = tref(P, op.out, boff);
@@ -1309,7 +1336,7 @@ int obb_set_option(obb_ctx *ctx, const char *key, int64_t value) {
         struct { const char *key; bool *flag; } sw[] = {
             {"tail", &ctx->opt.tail}, {"tail16", &ctx->opt.tail16}, {"bneck", &ctx->opt.bneck}, {"bneck_cv2", &ctx->opt.bneck_cv2},
             {"c3kimg", &ctx->opt.c3kimg}, {"dwpw", &ctx->opt.dwpw}, {"upfold", &ctx->opt.upfold}, {"stem", &ctx->opt.stem}, {"front", &ctx->opt.front}, {"pair", &ctx->opt.pair},
-            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"blk32", &ctx->opt.blk32}, {"c3k2f", &ctx->opt.c3k2f}, {"graph", &ctx->opt.graph}};
+            {"hmerge", &ctx->opt.hmerge}, {"sppf_fuse", &ctx->opt.sppf_fuse}, {"attn_mfma", &ctx->opt.attn_mfma}, {"xtile", &ctx->opt.xtile}, {"nitile", &ctx->opt.nitile}, {"nc2", &ctx->opt.nc2}, {"blk32", &ctx->opt.blk32}, {"c3k2f", &ctx->opt.c3k2f}, {"pw32", &ctx->opt.pw32}, {"graph", &ctx->opt.graph}};
         for (auto &e : sw)
             if (k == e.key) { *e.flag = value != 0; return OBB_OK; }
         if (k == "fuse") return OBB_OK;  // (retired: the LDS-resident layer chains were slower than layer-by-layer on MI355X and are gone)
@@ -1454,6 +1481,10 @@ int obb_debug_plan(obb_ctx *ctx, int32_t h, int32_t w, char *buf, int64_t buf_by
             case OP_SPPF: snprintf(line, sizeof line, "pool %s c%d out%dx%d x3 macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_POOL: snprintf(line, sizeof line, "pool %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
             case OP_UP: snprintf(line, sizeof line, "upsample %s c%d out%dx%d macs0\n", op.name.c_str(), op.in.C, op.Ho, op.Wo); break;
+            case OP_PW32:
+                snprintf(line, sizeof line, "pw32 %s k1 s1 cin%d cout%d out%dx%d waves%d lds%d macs%.0f\n", op.name.c_str(), op.pw32.cin, op.pw32.cout, op.Ho, op.Wo,
+                         op.pw32.cin * 256 <= 80 * 1024 ? 8 : 16, op.pw32.cin * 256, op.macs);
+                break;
             case OP_C3K2F32: {
                 int th, tw;
                 c3k2f32_tile(op.H, op.W, th, tw);

@@ -535,7 +535,7 @@ def gather_compact(recv):
 
 PRECISIONS = {"f16": 16, "fp16": 16, "bf16": 1016, "f32": 32, "fp32": 32}
 # engine switches of obb_set_option (each restores the separate launches of one fused form; used by the A/B parity tests)
-MODEL_OPTIONS = ("fuse", "tail", "tail16", "bneck", "bneck_cv2", "c3kimg", "dwpw", "upfold", "stem", "front", "pair", "hmerge", "sppf_fuse", "attn_mfma", "xtile", "nitile", "nc2", "blk32", "c3k2f", "graph")
+MODEL_OPTIONS = ("fuse", "tail", "tail16", "bneck", "bneck_cv2", "c3kimg", "dwpw", "upfold", "stem", "front", "pair", "hmerge", "sppf_fuse", "attn_mfma", "xtile", "nitile", "nc2", "blk32", "c3k2f", "pw32", "graph")
 
 
 def select_model(slot, device=None):
@@ -548,7 +548,7 @@ def model_load(blob, device=None, precision="f16", fuse=False, tail=True, **opti
     fp32 accumulation, "f32" = fp32 arithmetic end to end (what the reference computes; one kernel per layer).
     tail=False keeps the final 1x1 conv of each head branch a separate launch and turns every other intermediate-swallowing fusion off
     (every layer observable).  Further keyword switches (MODEL_OPTIONS, all default on except `fuse`) disable single fused forms:
-    tail16, bneck, bneck_cv2, c3kimg, dwpw, upfold, stem, front, pair, hmerge, sppf_fuse, attn_mfma, xtile, nitile, nc2, blk32, c3k2f."""
+    tail16, bneck, bneck_cv2, c3kimg, dwpw, upfold, stem, front, pair, hmerge, sppf_fuse, attn_mfma, xtile, nitile, nc2, blk32, c3k2f, pw32."""
     c = ctx(device)
     _call("obb_set_option", c, b"precision", PRECISIONS[precision])
     _call("obb_set_option", c, b"fuse", 1 if fuse else 0)

@@ -145,6 +145,28 @@ def test_fp32_channel_blocked_buffers_are_bit_identical(ood, nets, h, w, B, ch):
         assert torch.equal(t, ops.debug_activation(n, B, h, w).cpu()), n
 
 
+@pytest.mark.parametrize("h,w,B,ch", [(416, 416, 5, 3), (128, 128, 70, 3), (416, 288, 2, 3), (64, 96, 3, 3), (416, 416, 2, 4)])
+def test_fp32_direct_operand_1x1_is_bit_identical(ood, nets, h, w, B, ch):
+    """`pw32`: the 1x1 layers with >= 64 input channels on k_pw_f32 (weights of a 64-cout block resident in LDS, a lane's B operand loaded straight
+    from global memory, no activation staging, no barrier in the k loop) against k_conv_f32 (both operands staged through LDS): the same k order
+    (16-channel pieces, element s inside), the same epilogue -- heads and named 1x1 outputs BIT FOR BIT, incl. the residual layers of C2PSA, the
+    permuted qkv rows and the 8-channel-blocked outputs."""
+    ops = ood.ops
+    net = nets[416] if ch == 3 else Yolo11OBB("n", nc=12, ch=4, seed=3)
+    x = torch.as_tensor(_tiles(31 + h + B, B, h, w, ch)).cuda()
+    names = ("model.4.cv2", "model.6.cv2", "model.8.cv2", "model.9.cv2", "model.10.m.0.attn.qkv", "model.10.m.0.ffn.1", "model.10.cv2", "model.13.cv2", "model.19.cv2", "model.22.cv2")
+    ops.model_load(net.to_blob(), precision="f32", pw32=False)
+    assert not any(l.startswith("pw32 ") for l in ops.debug_plan(h, w))
+    staged = ops.forward(x).cpu()
+    taps = {n: ops.debug_activation(n, B, h, w).cpu() for n in names}
+    ops.model_load(net.to_blob(), precision="f32")
+    assert sum(l.startswith("pw32 ") for l in ops.debug_plan(h, w)) >= 20, ops.debug_plan(h, w)
+    direct = ops.forward(x).cpu()
+    for n, t in taps.items():
+        assert torch.equal(t, ops.debug_activation(n, B, h, w).cpu()), n
+    assert torch.equal(staged[..., :77], direct[..., :77]), float((staged - direct)[..., :77].abs().max())
+
+
 def test_rounds_are_sized_by_pixels_and_do_not_change_results(ood, nets):
     """A round of the forward holds 1024 tiles of 416 x 416 or proportionally more smaller ones (at most 8192): 8200 tiles of 64 x 64 are two
     rounds (8192 + 8); every tile's head must equal what the same tile gives in a small batch of its own."""

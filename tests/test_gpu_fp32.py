@@ -121,10 +121,11 @@ def test_fp32_two_fragment_form_is_bit_identical(ood, nets, h, w, B):
     ops.model_load(net.to_blob(), precision="f32", nc2=False)
     assert not any(" NC2 " in l for l in ops.debug_plan(h, w))
     one = ops.forward(x).cpu()
-    ops.model_load(net.to_blob(), precision="f32")
-    assert sum(" NC2 " in l for l in ops.debug_plan(h, w)) >= 10, ops.debug_plan(h, w)
-    two = ops.forward(x).cpu()
-    assert torch.equal(one[..., :77], two[..., :77]), float((one - two)[..., :77].abs().max())
+    for kw, least in ((dict(pw32=False), 10), ({}, 3)):  # (the 1x1 layers with >= 64 input channels go to k_pw_f32 by default)
+        ops.model_load(net.to_blob(), precision="f32", **kw)
+        assert sum(" NC2 " in l for l in ops.debug_plan(h, w)) >= least, ops.debug_plan(h, w)
+        two = ops.forward(x).cpu()
+        assert torch.equal(one[..., :77], two[..., :77]), float((one - two)[..., :77].abs().max())
 
 
 @pytest.mark.parametrize("h,w,B,ch", [(416, 416, 5, 3), (128, 128, 33, 3), (416, 288, 2, 3), (64, 96, 3, 3), (416, 416, 3, 4)])

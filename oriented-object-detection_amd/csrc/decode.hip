@@ -8,6 +8,7 @@
 // SURVEY.md Appendix A2/A4/A6.  These are HBM/latency-bound kernels: one workgroup per tile, candidates kept in
 // anchor order by ballot/prefix-sum compaction so that ties sort exactly like a stable argsort.
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 
@@ -302,8 +303,9 @@ __global__ __launch_bounds__(1024) void k_nms_tile(const float *__restrict__ pre
 //   2. DFL / dist2rbox / angle for the survivors only (decode_anchor: the code k_decode runs);
 //   3. stable rank sort, covariance terms, Fast-NMS and the max_det cut on LDS arrays of kCandCap rows.
 // A tile with more than kCandCap candidates (a saturated tile, or metrics mode at conf 0.001) is appended to a device-side list and
-// finished by three kernels that spread ONE tile over many workgroups (k_heavy_sort / k_heavy_nms / k_heavy_out): its O(n^2) rank sort
-// and pair loop are row-parallel, so the slowest tile no longer sets the time of the whole call.  Results are identical to the full
+// finished by kernels that spread ONE tile over many workgroups, so that the slowest tile no longer sets the time of the whole call:
+// k_heavy_prep + k_heavy_rows (sort-free, every candidate of the tile in LDS: predict-mode thresholds, tiles up to ~4300 anchors),
+// k_heavy_sort / k_heavy_nms / k_heavy_out (larger inputs) or the round form (metrics mode).  Results are identical to the full
 // decode + k_nms_tile path (kept as the parity reference in tests): same candidates, same arithmetic, same order.
 static constexpr int kCandCap = 256;
 static constexpr int kHeavySlots = 64;   // flagged tiles are walked by this many block columns (grid-stride)
@@ -322,6 +324,7 @@ struct HeavyScratch {  // per tile, stride AS rows (AS = A rounded up to 4)
     int32_t *sidx;     // sorted order: position in the candidate list
     int32_t *nkept;    // [B] kept rows of the rounds processed so far
     int32_t *done;     // [B] snapshot of nkept >= max_det taken between rounds
+    int32_t *wbase;    // [B + 1] k_heavy_rows: first work item of flagged tile f (prefix sums of the tiles' workgroup shares)
 };
 
 // class scores of one anchor: three 16-byte loads instead of nc scalar ones (rows are padded to a multiple of 4 floats, columns past nc
@@ -369,33 +372,70 @@ __global__ __launch_bounds__(256) void k_cand_nms(const float *__restrict__ head
 
     // 1. candidates in anchor order
     int n = 0;
-    for (int a0 = 0; a0 < A; a0 += NT) {
-        const int a = a0 + tid;
-        float best = -INFINITY;
-        int bj = 0;
-        if (a < A) {
-            const float *cp = hb + (int64_t)a * no + 4 * kRegMaxD;
-            // (cmax: the forward's per-anchor maximum of these logits, dense -- 4 bytes per anchor instead of a 48-byte piece of every
-            // 320-byte row; the rows of the few anchors above the gate are then read as before: the same values, the same decisions)
-            if constexpr (WIDE) { if (!cmax || cmax[(int64_t)b * A + a] > logit_gate) class_best(cp, nc, logit_gate, best, bj); }
-            else {
+    if constexpr (WIDE) {
+        // Two passes per 4096 anchors, so that the scan pays two memory latencies instead of one per 256 anchors: (a) the gate -- cmax, the
+        // forward's per-anchor maximum of the class logits (dense: 4 bytes per anchor instead of a 48-byte piece of every 320-byte row), all
+        // 16 values of a thread loaded up front; without cmax every anchor passes -- compacted in anchor order into an LDS list; (b) the exact
+        // class scores of the listed anchors (class_best: the same values and decisions as before), compacted again into the candidates.
+        __shared__ uint16_t gl[4096];
+        for (int a00 = 0; a00 < A; a00 += 4096) {
+            float cm[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int a = a00 + k * NT + tid;
+                cm[k] = (cmax && a < A) ? cmax[(int64_t)b * A + a] : INFINITY;
+            }
+            int ng = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (a00 + k * NT >= A) break;  // (uniform)
+                const int a = a00 + k * NT + tid;
+                const bool flag = (a < A) && (cm[k] > logit_gate);
+                const int slot = ordered_slot(flag, wave_tot, ng);
+                if (flag) gl[slot] = (uint16_t)(a - a00);
+            }
+            __syncthreads();
+            for (int k0 = 0; k0 < ng; k0 += NT) {
+                const int k = k0 + tid;
+                float best = -INFINITY;
+                int bj = 0, a = 0;
+                if (k < ng) {
+                    a = a00 + gl[k];
+                    class_best(hb + (int64_t)a * no + 4 * kRegMaxD, nc, logit_gate, best, bj);
+                }
+                const bool flag = (k < ng) && (best > conf_thres);
+                const int slot = ordered_slot(flag, wave_tot, n);
+                if (flag) {
+                    gcand[slot] = a; gscore[slot] = best; gcls[slot] = (uint8_t)bj;  // (the copy a tile above kCandCap is finished from)
+                    if (slot < kCandCap) { cand[slot] = a; cscore[slot] = best; ccls[slot] = (uint8_t)bj; }
+                }
+            }
+            __syncthreads();  // gl is rewritten by the next 4096 anchors
+        }
+    } else {
+        for (int a0 = 0; a0 < A; a0 += NT) {
+            const int a = a0 + tid;
+            float best = -INFINITY;
+            int bj = 0;
+            if (a < A) {
+                const float *cp = hb + (int64_t)a * no + 4 * kRegMaxD;
                 float mx = -INFINITY;
                 for (int j = 0; j < nc; ++j) mx = fmaxf(mx, cp[j]);
                 if (mx > logit_gate)
                     for (int j = 0; j < nc; ++j) { const float v = sigmoid_f(cp[j]); if (v > best) { best = v; bj = j; } }
             }
-        }
-        const bool flag = (a < A) && (best > conf_thres);
-        const int slot = ordered_slot(flag, wave_tot, n);
-        if (flag) {
-            gcand[slot] = a; gscore[slot] = best; gcls[slot] = (uint8_t)bj;  // (the copy a tile above kCandCap is finished from)
-            if (slot < kCandCap) { cand[slot] = a; cscore[slot] = best; ccls[slot] = (uint8_t)bj; }
+            const bool flag = (a < A) && (best > conf_thres);
+            const int slot = ordered_slot(flag, wave_tot, n);
+            if (flag) {
+                gcand[slot] = a; gscore[slot] = best; gcls[slot] = (uint8_t)bj;
+                if (slot < kCandCap) { cand[slot] = a; cscore[slot] = best; ccls[slot] = (uint8_t)bj; }
+            }
         }
     }
     __syncthreads();
     if (n == 0) { if (tid == 0) count[b] = 0; return; }
     if (n > kCandCap) {  // handed to the row-parallel kernels
-        if (tid == 0) { S.ncand[b] = n; S.flist[atomicAdd(S.nflag, 1)] = b; count[b] = 0; }
+        if (tid == 0) { S.ncand[b] = n; S.nkept[b] = 0; S.flist[atomicAdd(S.nflag, 1)] = b; count[b] = 0; }  // (nkept: k_heavy_rows' arrival counter)
         return;
     }
 
@@ -688,6 +728,258 @@ __global__ __launch_bounds__(256) void k_heavy_out(int A, int max_det, int max_n
     }
 }
 
+// ---- the LDS-resident, SORT-FREE form of the all-rows heavy path (k_heavy_prep + k_heavy_rows instead of k_heavy_sort + k_heavy_nms +
+//      k_heavy_out).  Those three are each the latency of their slowest tile -- a 2000-candidate tile: an O(n^2) rank count (83 us), then ~8 rows
+//      per wave with up to 8 dependent global loads each (97 us), then the compaction -- 185 us per 1024 tiles of which 36 are flagged.
+// Fast-NMS keeps row r iff NO candidate that precedes it in (score descending, position ascending) order overlaps it: that is a property of
+// the SET of predecessors, so the rows need not be sorted to be judged -- only the survivors (a few dozen) need their rank for the output.
+//   k_heavy_prep   one thread per candidate of a flagged tile, in CANDIDATE order: decode_anchor (the code of every other path) -> covariance
+//                  terms (class offset applied) + decoded box, to global scratch;
+//   k_heavy_rows   a flagged tile of n candidates is shared by G ~ n^2 / 2^17 <= gridDim.y workgroups of 512 threads.  Each loads the tile's
+//                  terms, scores and classes into LDS (one array per term: a wave's 64 partners are 64 consecutive words; 37 bytes per
+//                  candidate, 131 KB for the 3549 anchors of a 416-px tile, + 16 KB of score histogram) and takes rows r = part, part + G, ...: a wave scans ALL n candidates,
+//                  256 per step, starting at r's own block (neighbouring anchors are the likeliest suppressors, and any hit ends the row),
+//                  testing "precedes r" on the scores; every operand is an LDS read.  The LAST workgroup to finish a tile (device-scope
+//                  counter) compacts the survivors in candidate order, ranks them among themselves and writes the first max_det rows.
+// Same candidates, same pair arithmetic, same rows as the three-kernel form (kept for inputs whose candidates do not fit the LDS, above
+// ~4300 anchors) and as obb_decode_nms_full (tests).
+__device__ __forceinline__ int heavy_share(int n, int gmax) { return max(1, min(gmax, (int)(((int64_t)n * n + (1 << 17) - 1) >> 17))); }
+static constexpr int kHeavyShareMax = 32;
+
+__global__ __launch_bounds__(256) void k_heavy_prep(const float *__restrict__ head, int A, int nc, int h, int w, HeavyScratch S) {
+    __shared__ int wave_tot[16];
+    const int no = (4 * kRegMaxD + nc + 1 + 3) / 4 * 4;
+    const int64_t AS = (A + 3) & ~3;
+    const int nflag = *S.nflag;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // the work list of k_heavy_rows: tile f owns items [wbase[f], wbase[f + 1])
+        int base = 0;
+        for (int f0 = 0; f0 < nflag; f0 += 256) {
+            const int f = f0 + threadIdx.x;
+            const int g = f < nflag ? heavy_share(S.ncand[S.flist[f]], kHeavyShareMax) : 0;
+            // exclusive prefix over the block (the ordered_slot pattern, with counts instead of flags)
+            int v = g;
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+            if (lane == 63) wave_tot[wv] = v;
+            __syncthreads();
+            int off = 0, tot = 0;
+            for (int k = 0; k < 4; ++k) { if (k < wv) off += wave_tot[k]; tot += wave_tot[k]; }
+            if (f < nflag) S.wbase[f] = base + off + v - g;
+            base += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) S.wbase[nflag] = base;
+    }
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int b = S.flist[f];
+        const int n = S.ncand[b];
+        const int64_t tb = (int64_t)b * AS;
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+            const int a = S.cand[tb + i];
+            const int cls = S.ccls[tb + i];
+            float x, y, ww, hh, t;
+            decode_anchor(head + ((int64_t)b * A + a) * no, a, nc, h, w, x, y, ww, hh, t);
+            const float c = (float)cls * kMaxWh;
+            S.rb[tb + i] = make_rbox(x + c, y + c, ww, hh, t);
+            float *sb = S.sbox + (tb + i) * 5;
+            sb[0] = x; sb[1] = y; sb[2] = ww; sb[3] = hh; sb[4] = t;
+        }
+    }
+}
+
+static constexpr int kHeavyRowsThreads = 512;
+static constexpr int kHeavyBins = 4096;
+// grid: resident workgroups (one per CU: the LDS), each walks work items w = blockIdx.x, + gridDim.x, ... -- no workgroup is launched for nothing
+__global__ __launch_bounds__(kHeavyRowsThreads) void k_heavy_rows(int A, float conf_thres, float iou_thres, int max_det, float kq, float bdmax, HeavyScratch S,
+                                                              float *__restrict__ out, int32_t *__restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    __shared__ int wave_tot[16];
+    __shared__ int s_last, s_tbin, s_next;
+    constexpr int NT = kHeavyRowsThreads, NWV = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t AS = (A + 3) & ~3;
+    float *lx = reinterpret_cast<float *>(hsm), *ly = lx + AS, *lA = ly + AS, *lB = lA + AS, *lC = lB + AS, *ldet = lC + AS, *ltr = ldet + AS, *ls = ltr + AS;
+    int32_t *surv = reinterpret_cast<int32_t *>(ls + AS);
+    uint8_t *lcls = reinterpret_cast<uint8_t *>(surv + AS);
+    const bool skip_other_cls = iou_thres > 1e-3f;
+    const int nflag = *S.nflag;
+    const int total = S.wbase[nflag];
+    for (int wi = blockIdx.x; wi < total; wi += gridDim.x) {
+        int lo = 0, hi = nflag;  // the tile of item wi: the last f with wbase[f] <= wi
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.wbase[mid] <= wi) lo = mid; else hi = mid; }
+        const int f = lo, part = wi - S.wbase[f], G = S.wbase[f + 1] - S.wbase[f];
+        const int b = S.flist[f];
+        const int n = S.ncand[b];
+        const int64_t tb = (int64_t)b * AS;
+        __syncthreads();  // the previous item's LDS is no longer read
+        if (tid == 0) s_next = 0;
+        for (int i = tid; i < n; i += NT) {
+            const RBox q = S.rb[tb + i];
+            lx[i] = q.x; ly[i] = q.y; lA[i] = q.A; lB[i] = q.B; lC[i] = q.C; ldet[i] = q.det; ltr[i] = q.tr;
+            ls[i] = S.cscore[tb + i];
+            lcls[i] = S.ccls[tb + i];
+        }
+        __syncthreads();
+        uint8_t *keep = S.keep + tb;
+        constexpr int U = 4, STEP = 64 * U;
+        const int nblk = (n + STEP - 1) / STEP;
+        // this workgroup's rows are r = part, part + G, ...; its waves take them one at a time from a shared counter (a kept row scans the whole
+        // tile, a suppressed one stops at its first hit: dealt out in a fixed pattern the slowest wave took 1.6x the average)
+        auto claim = [&]() -> int {  // the next row of this workgroup, the same in every lane of the wave
+            int j = 0;
+            if (lane == 0) j = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return part + G * __shfl(j, 0);
+        };
+        for (int r = claim(); r < n; r = claim()) {
+            const RBox q = {lx[r], ly[r], lA[r], lB[r], lC[r], ldet[r], ltr[r]};
+            const float sr = ls[r];
+            const uint8_t cq = lcls[r];
+            bool hit = false;
+            int blk = r / STEP;
+            for (int k = 0; k < nblk; ++k) {
+                // stage 1, branch-free: score / class / centre / trace of 256 candidates in one round of LDS reads -> who precedes r, has its
+                // class and is not far apart; stage 2 (a second round of reads + the pair test) for those lanes only -- about every other step
+                RBox p[U];
+                bool near[U];
+                bool some = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = blk * STEP + u * 64 + lane, ii = min(i, n - 1);
+                    const float si = ls[ii];
+                    const uint8_t ci = lcls[ii];
+                    p[u].x = lx[ii]; p[u].y = ly[ii]; p[u].tr = ltr[ii];
+                    const bool pred = (si > sr) | ((si == sr) & (i < r));  // i precedes r in the stable descending order
+                    near[u] = (i < n) & pred & !(skip_other_cls & (ci != cq)) & !far_apart(p[u], q, kq);
+                    some |= near[u];
+                }
+                bool hh = false;
+                if (__any(some)) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (near[u]) {
+                            const int ii = blk * STEP + u * 64 + lane;
+                            p[u].A = lA[ii]; p[u].B = lB[ii]; p[u].C = lC[ii]; p[u].det = ldet[ii];
+                            const int dec = bdmax > 0.0f ? probiou_fast_decision(p[u], q, bdmax) : 0;
+                            hh = hh || dec > 0 || (dec == 0 && probiou(p[u], q) >= iou_thres);
+                        }
+                    }
+                }
+                if (__ballot(hh)) { hit = true; break; }
+                if (++blk == nblk) blk = 0;
+            }
+            if (lane == 0) __hip_atomic_store(keep + r, (uint8_t)!hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written through: see below)
+        }
+        // ---- the last of the tile's G workgroups writes its rows.  The flags are the only data that crosses workgroups (and XCDs, each with
+        // its own L2): they are stored and loaded as device-scope atomics (written through / read past the L2), so that the hand-over needs
+        // no __threadfence() -- its write-back of the whole L2 cost 29 of this kernel's 105 us -- only "my stores have completed" before
+        // the arrival counter (a device-scope atomic itself).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&S.nkept[b], 1) == G - 1;
+        __syncthreads();
+        if (!s_last) continue;
+        // survivors in candidate order; with more than max_det of them only those in the top score bins can be output: a histogram of the
+        // scores' upper bits (positive floats order like their bit patterns) finds the bin where the count from the top reaches max_det, and
+        // exact ranks -- (score descending, position ascending) among ALL survivors = among those at or above that bin -- are counted for
+        // those only (a 2000-candidate tile of random boxes keeps 1300 rows: 1300^2 comparisons otherwise)
+        int32_t *hist = reinterpret_cast<int32_t *>(hsm + ((AS * 37 + 15) & ~(int64_t)15));  // (lx: the survivors' scores from here on -- the pair tests are over)
+        const unsigned bits0 = __float_as_uint(fmaxf(conf_thres, 0.0f));
+        const unsigned range = 0x3f800000u > bits0 ? 0x3f800000u - bits0 : 1u;
+        const int shift = max(0, 32 - __clz((int)range) - 12);  // (range >> shift) < 4096
+        for (int i = tid; i < kHeavyBins + 8; i += NT) hist[i] = 0;
+        int m = 0;
+        const uint32_t *keep32 = reinterpret_cast<const uint32_t *>(keep);  // (tb and the scratch base are multiples of 4)
+        for (int r0 = 0; r0 < n; r0 += 4 * NT) {  // four consecutive rows per thread and round: one 32-bit load of their flags
+            const int r4 = r0 + 4 * tid;
+            const uint32_t wv = r4 < n ? __hip_atomic_load(keep32 + (r4 >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            bool fl[4];
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fl[q] = (r4 + q < n) && ((wv >> (8 * q)) & 0xffu); c += fl[q]; }
+            int v = c;  // exclusive prefix of the counts over the workgroup (the ordered_slot pattern)
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+            if (lane == 63) wave_tot[wave] = v;
+            __syncthreads();
+            int off = 0, tot = 0;
+            for (int q = 0; q < NWV; ++q) { if (q < wave) off += wave_tot[q]; tot += wave_tot[q]; }
+            int slot = m + off + v - c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (fl[q]) { surv[slot] = r4 + q; lx[slot] = ls[r4 + q]; ++slot; }
+            m += tot;
+            __syncthreads();
+        }
+        __syncthreads();
+        int m2 = m;
+        if (m > max_det) {
+            for (int k = tid; k < m; k += NT) {
+                const unsigned sb = __float_as_uint(lx[k]);
+                atomicAdd(&hist[min(kHeavyBins, (int)((sb > bits0 ? sb - bits0 : 0u) >> shift))], 1);
+            }
+            __syncthreads();
+            {   // thread t owns the PER bins below kHeavyBins - PER t (from the top): where does the count from the top reach max_det?
+                constexpr int PER = (kHeavyBins + 1 + NT - 1) / NT;
+                const int top = kHeavyBins - tid * PER;
+                int mine = 0;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) { const int bin = top - j; if (bin >= 0) mine += hist[bin]; }
+                int incl = mine;
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                if (lane == 63) wave_tot[wave] = incl;
+                __syncthreads();
+                int off = 0;
+                for (int q = 0; q < NWV; ++q) if (q < wave) off += wave_tot[q];
+                incl += off;
+                const int before = incl - mine;  // survivors in the bins above this thread's
+                if (before < max_det && incl >= max_det) {
+                    int acc = before, tb_ = 0;
+                    for (int j = 0; j < PER; ++j) { const int bin = top - j; if (bin < 0) break; acc += hist[bin]; tb_ = bin; if (acc >= max_det) break; }
+                    s_tbin = tb_;
+                }
+                __syncthreads();
+            }
+            const int tbin = s_tbin;
+            // second compaction (in place: slot <= k): the survivors at or above the threshold bin, still in candidate order
+            m2 = 0;
+            for (int k0 = 0; k0 < m; k0 += NT) {
+                const int k = k0 + tid;
+                int r = 0; float sc = 0.f; bool flag = false;
+                if (k < m) {
+                    r = surv[k]; sc = lx[k];
+                    const unsigned sb = __float_as_uint(sc);
+                    flag = min(kHeavyBins, (int)((sb > bits0 ? sb - bits0 : 0u) >> shift)) >= tbin;
+                }
+                const int slot = ordered_slot(flag, wave_tot, m2);  // (barriers inside: every read of this chunk is done before a write)
+                if (flag) { surv[slot] = r; lx[slot] = sc; }
+            }
+            __syncthreads();
+        }
+        // exact ranks among the m2 rows left, four scores per LDS read (padding: -inf never precedes anything)
+        for (int k = m2 + tid; k < ((m2 + 3) & ~3); k += NT) lx[k] = -INFINITY;
+        __syncthreads();
+        float *ob = out + (int64_t)b * max_det * 7;
+        for (int k = tid; k < m2; k += NT) {
+            const int r = surv[k];
+            const float sr = lx[k];
+            int rank = 0;
+            for (int j = 0; j < m2; j += 4) {
+                const float4 sj = *reinterpret_cast<const float4 *>(lx + j);
+                rank += (sj.x > sr) | ((sj.x == sr) & (j < k));
+                rank += (sj.y > sr) | ((sj.y == sr) & (j + 1 < k));
+                rank += (sj.z > sr) | ((sj.z == sr) & (j + 2 < k));
+                rank += (sj.w > sr) | ((sj.w == sr) & (j + 3 < k));
+            }
+            if (rank < max_det) {
+                const float *sb = S.sbox + (tb + r) * 5;
+                float *o = ob + (int64_t)rank * 7;
+                o[0] = sb[0]; o[1] = sb[1]; o[2] = sb[2]; o[3] = sb[3];
+                o[4] = sr; o[5] = (float)lcls[r]; o[6] = sb[4];
+            }
+        }
+        if (tid == 0) count[b] = m < max_det ? m : max_det;
+    }
+}
+
 // stand-alone Fast-NMS on a caller-provided candidate list (parity tap): boxes [n,5], scores [n]
 __global__ __launch_bounds__(256) void k_probiou_nms_list(const float *__restrict__ boxes, const float *__restrict__ scores, int n, float thr,
                                                          int32_t *__restrict__ order, uint8_t *__restrict__ keep, RBox *__restrict__ rb) {
@@ -837,11 +1129,11 @@ int obb_decode_nms_gate(obb_ctx *ctx, const float *head, const float *cmax, int3
     S.sbox = (float *)ctx->workspace(WS_NMS_D, rows * 20);
     S.rb = (RBox *)ctx->workspace(WS_GEOM_A, rows * sizeof(RBox));
     uint8_t *bytes = (uint8_t *)ctx->workspace(WS_GEOM_B, rows * 3);
-    int32_t *ints = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)4 * B + 64));
+    int32_t *ints = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)5 * B + 128));
     S.sidx = (int32_t *)ctx->workspace(WS_GEOM_D, rows * 4);
     if (!S.cand || !S.cscore || !S.sscore || !S.sbox || !S.rb || !bytes || !ints || !S.sidx) return set_error(ctx, OBB_ERR_HIP, "obb_decode_nms: workspace allocation failed");
     S.ccls = bytes; S.scls = bytes + rows; S.keep = bytes + 2 * rows;
-    S.ncand = ints; S.flist = ints + B; S.nkept = ints + 2 * (size_t)B; S.done = ints + 3 * (size_t)B; S.nflag = ints + 4 * (size_t)B;
+    S.ncand = ints; S.flist = ints + B; S.nkept = ints + 2 * (size_t)B; S.done = ints + 3 * (size_t)B; S.wbase = ints + 4 * (size_t)B; S.nflag = ints + 5 * (size_t)B + 64;
     OBB_HIP(ctx, hipMemsetAsync(S.nflag, 0, sizeof(int32_t), st));
     // largest logit an anchor needs to be worth the exact class scores: logit(conf) minus a guard band far above the error of sigmoid_f
     float gate = -INFINITY;
@@ -881,7 +1173,31 @@ int obb_decode_nms_gate(obb_ctx *ctx, const float *head, const float *cmax, int3
             OBB_LAUNCH_CHECK(ctx);
             r0 = r1;
         }
-    } else {  // the all-rows form (also: more anchors than the LDS sort takes, inputs above ~900 x 900)
+    } else {  // the all-rows form
+        const size_t AS = (size_t)((A + 3) & ~3);
+        const size_t lds = ((AS * 37 + 15) & ~(size_t)15) + (kHeavyBins + 8) * 4;  // seven covariance terms + score + survivor list + class per candidate | score histogram
+        if (lds <= 156 * 1024) {  // every candidate of a tile fits the LDS: two launches, the output included
+            static std::mutex mu;
+            static size_t attr_lds = 0;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (lds > attr_lds) {
+                    OBB_HIP(ctx, hipFuncSetAttribute((const void *)k_heavy_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_lds = lds;
+                }
+            }
+            hipLaunchKernelGGL(k_heavy_prep, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, S);
+            OBB_LAUNCH_CHECK(ctx);
+            int ncu = 0, dev = 0;
+            OBB_HIP(ctx, hipGetDevice(&dev));
+            OBB_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            const int resident = std::max(1, ncu) * (int)std::max<size_t>(1, (160 * 1024) / (lds + 128));
+            hipLaunchKernelGGL(k_heavy_rows, dim3((unsigned)std::min<int64_t>(resident, (int64_t)B * kHeavyShareMax)), dim3(kHeavyRowsThreads), lds, st, A, conf_thres, iou_thres,
+                               max_det, kq, bdmax, S, out, count);
+            OBB_LAUNCH_CHECK(ctx);
+            return OBB_OK;
+        }
+        // (more anchors than that -- inputs above ~500 x 500: rank sort from global scores, rows spread over 64 x 4 waves per tile)
         hipLaunchKernelGGL(k_heavy_sort, dim3((unsigned)slots, (unsigned)std::min<int64_t>(16, cdiv(A, 256))), dim3(256), 0, st, head, A, nc, h, w, 30000, S);
         OBB_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(k_heavy_nms, dim3((unsigned)slots, 64), dim3(256), 0, st, A, iou_thres, 30000, kq, bdmax, S);

@@ -84,6 +84,31 @@ def test_candidate_first_path_equals_the_full_decode(ops, net, conf, max_det):
         assert ncand.min() == 0 and ncand.max() > 2048 and ((ncand > 0) & (ncand <= 256)).any() and ((ncand > 256) & (ncand < 2048)).any()
 
 
+@pytest.mark.parametrize("h,w,B", [(416, 416, 150), (640, 640, 6), (128, 128, 70)])
+def test_flagged_tiles_in_both_heavy_forms_equal_the_full_decode(ops, net, h, w, B):
+    """Tiles above 256 candidates: the LDS-resident sort-free form (k_heavy_prep + k_heavy_rows: a 416-px tile's 3549 candidates fit; 150 tiles = block
+    columns that walk several flagged tiles, shared by 1..32 workgroups each) and the three-kernel form that larger inputs fall back to
+    (640 px: 8400 anchors) against obb_decode_nms_full, bit for bit, on random heads with 0 .. every anchor a candidate."""
+    A = ops.model_info(h, w)["anchors"]
+    g = torch.Generator(device="cuda").manual_seed(h + B)
+    head = torch.randn((B, A, 80), generator=g, device="cuda")
+    head[..., :64] *= 2.0
+    shift = torch.linspace(-6.0, 3.0, B, device="cuda")[torch.randperm(B, generator=g, device="cuda")]
+    head[..., 64:76] += shift[:, None, None]
+    head[..., 76] *= 0.5
+    for conf, max_det in ((0.25, 300), (0.6, 40)):
+        det, cnt = ops.decode_nms(head, h, w, conf, 0.7, max_det)
+        det_f, cnt_f = ops.decode_nms(head, h, w, conf, 0.7, max_det, full=True)
+        assert torch.equal(cnt, cnt_f), (cnt.tolist(), cnt_f.tolist())
+        for b in range(B):
+            n = int(cnt[b])
+            assert torch.equal(det[b, :n], det_f[b, :n]), (conf, b)
+        ncand = (torch.sigmoid(head[..., 64:76]).amax(-1) > conf).sum(1).cpu().numpy()
+        print(h, w, "conf", conf, "flagged tiles", int((ncand > 256).sum()), "largest", int(ncand.max()), "rows", int(cnt.sum()))
+        if conf == 0.25:
+            assert (ncand > 256).sum() >= (3 if A > 1000 else 1) and ncand.min() < 256
+
+
 @pytest.mark.parametrize("precision,h,w,B", [("f32", 416, 416, 6), ("f32", 128, 128, 40), ("f32", 416, 288, 3), ("f16", 416, 416, 4)])
 def test_forward_gate_emits_the_class_maximum_and_decode_nms_gate_is_identical(ops, net, precision, h, w, B):
     """obb_forward_gate leaves cmax[b, a] = max over the class logits of head[b, a] (written by the fused class tails of the fp32 head -- DWConv

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(64) void k_dt_chamfer(const uint8_t *__restrict__ e
             }
         }
     }
-    __threadfence();  // the mirrored lane mapping below reads what other lanes stored
+    __threadfence_block();  // the mirrored lane mapping below reads what other lanes OF THIS WAVE stored: their completion is all it needs (the
+                            // CU's L1 is coherent for its own waves; a device-scope fence writes back the whole L2 -- measured at 29 us in k_heavy_rows)
     {  // ---- backward: rows bottom to top, scan right to left (lane 0 owns the rightmost chunk)
         const int x0 = (63 - lane) * PX;
         int prev[PX];

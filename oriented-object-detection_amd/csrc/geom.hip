@@ -25,19 +25,21 @@ __global__ __launch_bounds__(256) void k_iou_pairs(const double *__restrict__ a,
                                                   double *__restrict__ out) {
     // stage 256 pairs x 2 x 64 B through LDS: global reads are contiguous 8 B/lane, LDS rows padded to 9 doubles so
     // that the per-thread row reads (stride 72 B) are bank-conflict free
-    __shared__ double sa[256 * 9], sb[256 * 9];
+    // (a lane's row of 18 doubles = quad a | pad | quad b | pad; once both quads are in registers the row is the lane's clip buffer:
+    // kClipCap vertices of 16 bytes -- see clip_area_convex)
+    __shared__ __attribute__((aligned(16))) double sab[256 * 18];
     int64_t base = (int64_t)blockIdx.x * 256;
     int nloc = (int)((m - base) < 256 ? (m - base) : 256);
     const double *ga = a + base * 8, *gb = b + base * 8;
     for (int e = threadIdx.x; e < nloc * 8; e += 256) {
-        sa[(e >> 3) * 9 + (e & 7)] = ga[e];
-        sb[(e >> 3) * 9 + (e & 7)] = gb[e];
+        sab[(e >> 3) * 18 + (e & 7)] = ga[e];
+        sab[(e >> 3) * 18 + 9 + (e & 7)] = gb[e];
     }
     __syncthreads();
     if ((int)threadIdx.x < nloc) {
         double pa[8], pb[8];
-        for (int k = 0; k < 8; ++k) { pa[k] = sa[threadIdx.x * 9 + k]; pb[k] = sb[threadIdx.x * 9 + k]; }
-        out[base + threadIdx.x] = poly_iou(pa, pb);
+        for (int k = 0; k < 8; ++k) { pa[k] = sab[threadIdx.x * 18 + k]; pb[k] = sab[threadIdx.x * 18 + 9 + k]; }
+        out[base + threadIdx.x] = poly_iou_lds(pa, pb, reinterpret_cast<P2 *>(sab + threadIdx.x * 18), 1);
     }
 }
 
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void k_iou_matrix(const double *__restrict__ a
     // block = 16 rows x 16.. cols tile: thread (ty, tx)
     __shared__ double sa[16 * 8], sb[16 * 8];
     __shared__ int32_t sca[16], scb[16];
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 256];  // lane-private clip buffers (clip_area_convex)
     int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
     if (threadIdx.x < 128) {
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void k_iou_matrix(const double *__restrict__ a
     int64_t i = i0 + ty, j = j0 + tx;
     if (i < na && j < nb) {
         double v = 0.0;
-        if (!(ca && cb) || sca[ty] == scb[tx]) v = poly_iou(&sa[ty * 8], &sb[tx * 8]);
+        if (!(ca && cb) || sca[ty] == scb[tx]) v = poly_iou_lds(&sa[ty * 8], &sb[tx * 8], sclip + threadIdx.x, 256);
         out[i * nb + j] = v;
     }
 }
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ s
                                                    const int32_t *__restrict__ members, const int32_t *__restrict__ large,
                                                    unsigned long long *__restrict__ edges, unsigned int *__restrict__ edge_count, unsigned int edge_cap) {
     __shared__ unsigned long long queue[4][128];
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 256];  // lane-private clip buffers (clip_area_convex)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridInfo g = *info;
     unsigned long long *q = queue[wave];
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ s
                 a[k].x = sboxes[lo * 8 + 2 * k]; a[k].y = sboxes[lo * 8 + 2 * k + 1];
                 b[k].x = sboxes[hi * 8 + 2 * k]; b[k].y = sboxes[hi * 8 + 2 * k + 1];
             }
-            if (poly_iou_core(a, b) >= thr) {
+            if (poly_iou_core_lds(a, b, sclip + threadIdx.x, 256) >= thr) {
                 const unsigned int slot = atomicAdd(edge_count, 1u);
                 if (slot < edge_cap) edges[slot] = pr;
             }
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sbox
     __shared__ int32_t cc[64];
     __shared__ unsigned long long bits[64];
     __shared__ unsigned short plist[4096];
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 64];  // lane-private clip buffers (clip_area_convex)
     int lane = threadIdx.x;
     int64_t i = (int64_t)ib * 64 + lane, j = (int64_t)jb * 64 + lane;
     BoxMeta rm;
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(64) void k_nms_mask(const double *__restrict__ sbox
             const double *pb = sboxes + ((int64_t)jb * 64 + c) * 8;
             P2 p[4], q[4];
             for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
-            double iou = poly_iou_core(p, q);
+            double iou = poly_iou_core_lds(p, q, sclip + lane, 64);
             if (iou >= thr) {
                 if constexpr (EDGES) {
                     unsigned int e = atomicAdd(edge_count, 1u);
@@ -704,7 +709,7 @@ static constexpr int kSegWords = kSegMax / 64;
 // One workgroup (1024 threads) per segment: rank sort, pair tests, greedy scan -- everything in LDS.
 // The cheap class + envelope tests emit a compact candidate-pair list; the expensive fp64 clipping is then spread evenly
 // over all lanes (a row-per-thread loop would leave most of the group idle behind the few crowded rows).
-static constexpr int kSegPairCap = 12288;
+static constexpr int kSegPairCap = 8192;
 static constexpr int kSegMid = 256, kSegMidPairCap = 4096;
 
 // Segment `seg` = rows [seg_lo[seg], seg_hi[seg]) (a prefix-offset array passes (off, off + 1); the fused per-tile path passes fixed-stride
@@ -727,6 +732,9 @@ __global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict_
     __shared__ unsigned long long sbits[kSegMax * kSegWords];
     __shared__ unsigned int spairs[kSegPairCap];
     __shared__ unsigned int npairs_s;
+    // lane-private clip buffers (clip_area_convex) for CLIPT lanes: the 1024-thread form clips with its first 512 threads (128 bytes per lane)
+    constexpr int CLIPT = NT < 512 ? NT : 512;
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * CLIPT];
     int seg = blockIdx.x;
     int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     int n = s1 - s0;
@@ -796,12 +804,12 @@ __global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict_
     __syncthreads();
     // phase B: exact fp64 clipping, one candidate pair per lane
     int npairs = (int)min(npairs_s, (unsigned)kSegPairCap);
-    for (int t = threadIdx.x; t < npairs; t += NT) {
+    for (int t = threadIdx.x; t < npairs && (int)threadIdx.x < CLIPT; t += CLIPT) {
         int i = spairs[t] >> 16, j = spairs[t] & 0xffff;
         P2 p[4], q[4];
         const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8, *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
         for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
-        if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
+        if (poly_iou_core_lds(p, q, sclip + threadIdx.x, CLIPT) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // wave 0: lane w owns word w of `removed`
@@ -836,6 +844,7 @@ __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__rest
     __shared__ unsigned long long sbits[kSegWave];
     __shared__ unsigned short spairs[kSegWave * (kSegWave - 1) / 2];
     __shared__ unsigned int npairs_s;
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 64];  // lane-private clip buffers (clip_area_convex)
     const int seg = blockIdx.x, t = threadIdx.x;
     const int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     const int n = s1 - s0;
@@ -882,7 +891,7 @@ __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__rest
         const int i = spairs[e] >> 8, j = spairs[e] & 0xff;
         P2 p[4], q[4];
         for (int k = 0; k < 4; ++k) { p[k].x = sbox[i * 8 + 2 * k]; p[k].y = sbox[i * 8 + 2 * k + 1]; q[k].x = sbox[j * 8 + 2 * k]; q[k].y = sbox[j * 8 + 2 * k + 1]; }
-        if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i], 1ull << j);
+        if (poly_iou_core_lds(p, q, sclip + t, 64) >= thr) atomicOr(&sbits[i], 1ull << j);
     }
     __syncthreads();
     unsigned long long rem = 0ull;  // wave-uniform greedy scan
@@ -908,6 +917,7 @@ __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ bo
     __shared__ double r_conf[256], r_iou[256];
     __shared__ int32_t r_idx[256];
     __shared__ int32_t nout_s;
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 256];  // lane-private clip buffers (clip_area_convex)
     int64_t total = off[nscales];
     int tid = threadIdx.x;
     if (tid == 0) nout_s = 0;
@@ -942,7 +952,7 @@ __global__ __launch_bounds__(256) void k_consensus(const double *__restrict__ bo
                 if (meta_overlap(mi, meta[j])) {
                     P2 q[4];
                     for (int k = 0; k < 4; ++k) { q[k].x = boxes[j * 8 + 2 * k]; q[k].y = boxes[j * 8 + 2 * k + 1]; }
-                    iou = poly_iou_core(p, q);
+                    iou = poly_iou_core_lds(p, q, sclip + tid, 256);
                 }
                 if (iou >= iou_partner) {
                     double cp = conf[j];
@@ -1022,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_cons_edges(const double *__restrict__ b
     __shared__ BoxMeta sm[64];
     __shared__ int32_t sc[64];
     __shared__ int16_t ss[64];  // scale id, or -1 for a detection that takes no part (below CONS_LOW)
+    __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 256];  // lane-private clip buffers (clip_area_convex)
     const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 256;
     if (j0 + 255 <= i0) return;  // no pair with i < j in this block
     if (threadIdx.x < 64) {
@@ -1047,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_cons_edges(const double *__restrict__ b
         }
         // the walk evaluates compute_polygon_iou(d, p) with d = the detection being processed: the earlier one (i) in every pair that
         // can matter (a later detection never looks back at a visited one), so (i, j) is the argument order to reproduce bit for bit
-        const double iou = poly_iou_core(p, q);
+        const double iou = poly_iou_core_lds(p, q, sclip + threadIdx.x, 256);
         if (!(iou >= iou_thr)) continue;
         const int a = atomicAdd(&deg[i], 1), b = atomicAdd(&deg[j], 1);
         if (a < kConsK) { adj_idx[i * kConsK + a] = (int32_t)j; adj_iou[i * kConsK + a] = iou; } else flags[0] = 1;

@@ -168,6 +168,104 @@ __device__ inline double poly_iou_core(const P2 *p, const P2 *q) {
     return uni > 0.0 ? inter / uni : 0.0;
 }
 
+// ---- the same clip without private-memory arrays.  clip_area's two 16-vertex buffers are indexed by run-time counters, so the compiler
+// keeps them in scratch (976 bytes per lane in every kernel that clips): each vertex is a round trip through the memory hierarchy, ~60 us
+// for one quad pair per lane of a 1024-thread workgroup.  For two CONVEX quads -- every rotated rectangle -- a Sutherland-Hodgman stage
+// adds at most one vertex (<= 5 + e after clip edge e), so: the stage's input lives in registers (static indices, fully unrolled), its
+// output is appended to a lane-private LDS buffer of kClipCap vertices (the only run-time index) and read back into the registers with
+// static offsets.  Every expression and the order of the shoelace sum are those of clip_area: the result is bit-identical.
+// A sign pattern that only rounding can produce (more than one extra vertex at a stage) or a concave operand takes the general routine.
+static constexpr int kClipCap = 8;
+
+// lbuf: this lane's kClipCap vertices, vertex k at lbuf[k * lstride].  ok = false: not representable here (the caller falls back).
+__device__ __forceinline__ double clip_area_convex(const P2 *subj, const P2 *clip, P2 *lbuf, int lstride, bool &ok) {
+    P2 in[kClipCap];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in[i] = subj[i];
+#pragma unroll
+    for (int i = 4; i < kClipCap; ++i) in[i] = subj[0];
+    int n = 4;
+    P2 last = subj[3];
+    ok = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const P2 a = clip[e], b = clip[(e + 1) & 3];
+        int m = 0;
+        P2 s = last;
+        double ds = cross3(a, b, s);
+#pragma unroll
+        for (int i = 0; i < 4 + e; ++i) {
+            if (i < n) {
+                const P2 p = in[i];
+                const double dp = cross3(a, b, p);
+                if (dp >= 0.0) {
+                    if (ds < 0.0) {
+                        const double t = ds / (ds - dp);
+                        P2 v;
+                        v.x = s.x + (p.x - s.x) * t;
+                        v.y = s.y + (p.y - s.y) * t;
+                        lbuf[min(m, kClipCap - 1) * lstride] = v;
+                        ++m;
+                    }
+                    lbuf[min(m, kClipCap - 1) * lstride] = p;
+                    ++m;
+                    last = p;
+                } else if (ds >= 0.0) {
+                    const double t = ds / (ds - dp);
+                    P2 v;
+                    v.x = s.x + (p.x - s.x) * t;
+                    v.y = s.y + (p.y - s.y) * t;
+                    lbuf[min(m, kClipCap - 1) * lstride] = v;
+                    ++m;
+                    last = v;
+                }
+                s = p;
+                ds = dp;
+            }
+        }
+        if (m > 5 + e) ok = false;
+        n = min(m, 5 + e);
+#pragma unroll
+        for (int k = 0; k < 5 + e; ++k) in[k] = lbuf[k * lstride];
+    }
+    if (n < 3) return 0.0;
+    double sum = 0.0;  // shoelace2, vertex by vertex in the same order
+#pragma unroll
+    for (int i = 0; i < kClipCap; ++i)
+        if (i < n) {
+            const P2 pj = (i + 1 == n) ? in[0] : in[(i + 1) & (kClipCap - 1)];
+            sum += in[i].x * pj.y - pj.x * in[i].y;
+        }
+    return fabs(sum) * 0.5;
+}
+
+// poly_iou_core with the convex case clipped through the lane's LDS buffer
+__device__ inline double poly_iou_core_lds(const P2 *p, const P2 *q, P2 *lbuf, int lstride) {
+    P2 pc[4], qc[4];
+    const double sp = shoelace2<4>(p, 4), sq = shoelace2<4>(q, 4);
+    const bool rp = sp < 0.0, rq = sq < 0.0;  // make_ccw
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pc[i] = rp ? p[3 - i] : p[i]; qc[i] = rq ? q[3 - i] : q[i]; }
+    if (is_convex(pc, 4) && is_convex(qc, 4)) {
+        bool ok;
+        const double inter = clip_area_convex(pc, qc, lbuf, lstride, ok);
+        if (ok) {
+            const double a1 = fabs(sp) * 0.5, a2 = fabs(sq) * 0.5;
+            const double uni = a1 + a2 - inter;
+            return uni > 0.0 ? inter / uni : 0.0;
+        }
+    }
+    return poly_iou_core(p, q);
+}
+
+__device__ inline double poly_iou_lds(const double *b1, const double *b2, P2 *lbuf, int lstride) {
+    P2 p[4], q[4];
+    for (int i = 0; i < 4; ++i) { p[i].x = b1[2 * i]; p[i].y = b1[2 * i + 1]; q[i].x = b2[2 * i]; q[i].y = b2[2 * i + 1]; }
+    if (!quad_valid(p) || !quad_valid(q)) return 0.0;
+    if (aabb_disjoint(quad_aabb(p), quad_aabb(q))) return 0.0;
+    return poly_iou_core_lds(p, q, lbuf, lstride);
+}
+
 __device__ inline double poly_iou(const double *b1, const double *b2) {
     P2 p[4], q[4];
     for (int i = 0; i < 4; ++i) { p[i].x = b1[2 * i]; p[i].y = b1[2 * i + 1]; q[i].x = b2[2 * i]; q[i].y = b2[2 * i + 1]; }

@@ -51,8 +51,9 @@ def test_fp32_layer_taps(ood, nets):
     net.forward_raw(x, "fp32", taps)
     ops.model_load(net.to_blob(), precision="f32", tail=False, upfold=False, sppf_fuse=False, stem=False)  # one generic kernel per layer: every activation exists
     plan = ops.debug_plan(416, 416)
-    assert all(l.startswith(("conv32 ", "dwconv ", "pool ", "upsample ", "attn ", "total_macs")) for l in plan), plan
-    assert sum(l.startswith("conv32 ") for l in plan) == 96 - 7  # every dense conv of the blob (7 records are depthwise)
+    assert all(l.startswith(("conv32 ", "pw32 ", "dwconv ", "pool ", "upsample ", "attn ", "total_macs")) for l in plan), plan
+    assert sum(l.startswith(("conv32 ", "pw32 ")) for l in plan) == 96 - 7  # every dense conv of the blob (7 records are depthwise)
+    assert sum(l.startswith("pw32 ") for l in plan) >= 20                   # (the 1x1 layers with >= 64 input channels: k_pw_f32)
     assert not any(" tail" in l and " tail0 " not in l for l in plan if l.startswith("conv32 ")) and not any(" vcat1" in l for l in plan)
     ops.forward(torch.as_tensor(x).cuda())
     torch.cuda.synchronize()

@@ -720,22 +720,20 @@ static constexpr int kSegMid = 256, kSegMidPairCap = 4096;
 // threads: 256 threads took 372 us for what 1024 do in < 483 us, and the two launches add up.)  `skip_above` > 0: longer segments are
 // left to another launch
 template <int SEGMAX, int NT, int PAIRCAP>
-__global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
-                                                        const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
-                                                        double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
-                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto, int skip_above) {
+__device__ __forceinline__ void merge_segment(const int seg, const double *__restrict__ boxes, const int32_t *__restrict__ cls, const double *__restrict__ conf,
+                                              const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi, double thr, int32_t *__restrict__ order,
+                                              uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto, int skip_above) {
     constexpr int kSegMax = SEGMAX, kSegWords = SEGMAX / 64, kSegPairCap = PAIRCAP;
     __shared__ double skey[kSegMax];
     __shared__ int32_t sord[kSegMax];
     __shared__ int32_t scl[kSegMax];
     __shared__ BoxMeta smeta[kSegMax];
-    __shared__ unsigned long long sbits[kSegMax * kSegWords];
+    __shared__ __attribute__((aligned(16))) unsigned long long sbits[kSegMax * kSegWords];
     __shared__ unsigned int spairs[kSegPairCap];
     __shared__ unsigned int npairs_s;
     // lane-private clip buffers (clip_area_convex) for CLIPT lanes: the 1024-thread form clips with its first 512 threads (128 bytes per lane)
     constexpr int CLIPT = NT < 512 ? NT : 512;
     __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * CLIPT];
-    int seg = blockIdx.x;
     int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     int n = s1 - s0;
     if (n <= skip_upto) { if (n <= 0 && skip_upto == 0 && threadIdx.x == 0 && n_keep) n_keep[seg] = 0; return; }  // (short ones: k_merge_segments_wave)
@@ -767,37 +765,34 @@ __global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict_
         else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
         smeta[t] = m;
         scl[t] = cls[src];
-        for (int w = 0; w < W; ++w) sbits[t * kSegWords + w] = 0ull;
+        for (int w = 0; w < kSegWords; ++w) sbits[t * kSegWords + w] = 0ull;
     }
     __syncthreads();
     const bool all_hit = !(thr > 0.0);
-    // phase A: cheap tests over the strict upper triangle, flattened so that every lane gets the same number of pairs
-    const int npair_total = n * (n - 1) / 2;
-    for (int base = 0; base < npair_total; base += NT) {
-        int pidx = base + threadIdx.x;
-        bool cand = false;
-        int i = 0, j = 0;
-        if (pidx < npair_total) {
-            // row i of the triangle: first index f(i) = i*(2n-i-1)/2 ; invert with a float guess + fix-up
-            float fn = (float)n - 0.5f;
-            i = (int)(fn - sqrtf(fn * fn - 2.0f * (float)pidx));
-            if (i < 0) i = 0;
-            while (i > 0 && i * (2 * n - i - 1) / 2 > pidx) --i;
-            while ((i + 1) * (2 * n - i - 2) / 2 <= pidx) ++i;
-            j = pidx - i * (2 * n - i - 1) / 2 + i + 1;
-            if (scl[i] == scl[j]) {
-                if (all_hit) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
-                else cand = meta_overlap(smeta[i], smeta[j]);
-            }
-        }
-        if (cand) {
-            unsigned int slot = atomicAdd(&npairs_s, 1u);
-            if (slot < (unsigned)kSegPairCap) spairs[slot] = ((unsigned)i << 16) | (unsigned)j;
-            else {  // list full (pathologically crowded tile): clip right here
-                P2 p[4], q[4];
-                const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8, *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
-                for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
-                if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
+    // phase A: cheap tests (class, envelope) over the strict upper triangle -> candidate pairs.  Thread (j, part): row j against the earlier
+    // rows of slice `part` -- the row's own class and envelope stay in registers and a wave's lanes read the SAME earlier row (one LDS
+    // broadcast per test).  (The flattened triangle this replaces spent 60 us of a 290-row segment's 216 on inverting pair indices.)
+    {
+        const int npad = (n + 63) & ~63;               // whole waves per part
+        const int parts = max(1, NT / npad), chunk = (n + parts - 1) / parts;
+        for (int idx = threadIdx.x; idx < npad * parts; idx += NT) {
+            const int j = idx % npad, part = idx / npad;
+            if (j >= n) continue;
+            const int i0 = part * chunk, i1 = min(min(i0 + chunk, n), j);
+            const int cj = scl[j];
+            const BoxMeta mj = smeta[j];
+            for (int i = i0; i < i1; ++i) {
+                if (scl[i] != cj) continue;
+                if (all_hit) { atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63)); continue; }
+                if (!meta_overlap(smeta[i], mj)) continue;
+                const unsigned int slot = atomicAdd(&npairs_s, 1u);
+                if (slot < (unsigned)kSegPairCap) spairs[slot] = ((unsigned)i << 16) | (unsigned)j;
+                else {  // list full (pathologically crowded tile): clip right here (general routine: no LDS buffer for every thread)
+                    P2 p[4], q[4];
+                    const double *pa = boxes + (int64_t)(s0 + sord[i]) * 8, *pb = boxes + (int64_t)(s0 + sord[j]) * 8;
+                    for (int k = 0; k < 4; ++k) { p[k].x = pa[2 * k]; p[k].y = pa[2 * k + 1]; q[k].x = pb[2 * k]; q[k].y = pb[2 * k + 1]; }
+                    if (poly_iou_core(p, q) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
+                }
             }
         }
     }
@@ -812,20 +807,63 @@ __global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict_
         if (poly_iou_core_lds(p, q, sclip + threadIdx.x, CLIPT) >= thr) atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63));
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // wave 0: lane w owns word w of `removed`
-        int lane = threadIdx.x;
+    // greedy scan, wave 0, 64 rows at a time (one row per step -- shuffle, test, LDS read, or -- was 36 us for 290 rows).  Lane r holds the
+    // diagonal word of row i0 + r (whom it suppresses inside the block).  The kept set K of the block is the unique solution of
+    // K = alive & ~OR_{j in K} diag_j (the pair graph is acyclic: only earlier rows suppress), reached by iterating from K = alive -- row i is
+    // final after i + 1 rounds at the latest, in practice after the depth of the longest suppression chain (a few); then the kept rows' later
+    // words are OR-reduced over the wave into `removed` (lane w owns word w).
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        auto wave_or = [](unsigned long long v) -> unsigned long long {
+            unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, o); hi |= (unsigned)__shfl_xor((int)hi, o); }
+            return ((unsigned long long)hi << 32) | lo;
+        };
         unsigned long long rem = 0ull;
         int kept = 0;
-        for (int i = 0; i < n; ++i) {
-            unsigned long long wv = __shfl(rem, i >> 6);
-            bool k = !((wv >> (i & 63)) & 1ull);  // wave-uniform
-            if (k) {
-                if (lane < W) rem |= sbits[i * kSegWords + lane];
-                ++kept;
+        for (int b = 0; b < W; ++b) {
+            const int i0 = b * 64, r = i0 + lane;
+            const int nb = min(64, n - i0);
+            const unsigned long long valid = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+            const unsigned long long diag = r < n ? sbits[r * kSegWords + b] : 0ull;
+            const unsigned rlo = (unsigned)__shfl((int)(unsigned)rem, b), rhi = (unsigned)__shfl((int)(unsigned)(rem >> 32), b);
+            const unsigned long long alive = ~(((unsigned long long)rhi << 32) | rlo) & valid;  // not removed by an earlier block's rows
+            unsigned long long K = alive;
+            for (int it = 0; it < 64; ++it) {
+                const unsigned long long R = wave_or(((K >> lane) & 1ull) ? diag : 0ull);
+                const unsigned long long Kn = alive & ~R;
+                if (Kn == K) break;  // (uniform)
+                K = Kn;
             }
-            if (lane == 0) keep[s0 + i] = (uint8_t)k;
+            kept += __popcll(K);
+            const bool mine = (K >> lane) & 1ull;
+            if (r < n) keep[s0 + r] = (uint8_t)mine;
+            for (int w = b + 1; w < W; ++w) {  // later words: OR of the kept rows' bits
+                const unsigned long long v = wave_or(mine ? sbits[r * kSegWords + w] : 0ull);
+                if (lane == w) rem |= v;
+            }
         }
         if (lane == 0 && n_keep) n_keep[seg] = kept;
+    }
+}
+
+// grid: one workgroup per segment (work_list == nullptr), or resident workgroups walking the device-side list of the segments longer than a
+// wave takes (k_merge_segments_wave builds it): no 1024-thread, 155-KB workgroup is launched for a short segment only to return.
+template <int SEGMAX, int NT, int PAIRCAP>
+__global__ __launch_bounds__(NT) void k_merge_segments(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                        const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
+                                                        double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
+                                                        int32_t *__restrict__ n_keep, int32_t *__restrict__ status, int skip_upto, int skip_above,
+                                                        const int32_t *__restrict__ work_list, const int32_t *__restrict__ work_count) {
+    if (!work_list) {
+        merge_segment<SEGMAX, NT, PAIRCAP>(blockIdx.x, boxes, cls, conf, seg_lo, seg_hi, thr, order, keep, n_keep, status, skip_upto, skip_above);
+        return;
+    }
+    const int nw = *work_count;
+    for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+        merge_segment<SEGMAX, NT, PAIRCAP>(work_list[w], boxes, cls, conf, seg_lo, seg_hi, thr, order, keep, n_keep, status, skip_upto, skip_above);
+        __syncthreads();
     }
 }
 
@@ -835,7 +873,7 @@ static constexpr int kSegWave = 64;
 __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__restrict__ boxes, const int32_t *__restrict__ cls,
                                                            const double *__restrict__ conf, const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_hi,
                                                            double thr, int32_t *__restrict__ order, uint8_t *__restrict__ keep,
-                                                           int32_t *__restrict__ n_keep) {
+                                                           int32_t *__restrict__ n_keep, int32_t *__restrict__ long_list, int32_t *__restrict__ long_count) {
     __shared__ double skey[kSegWave];
     __shared__ int32_t sord[kSegWave];
     __shared__ int32_t scl[kSegWave];
@@ -849,7 +887,7 @@ __global__ __launch_bounds__(64) void k_merge_segments_wave(const double *__rest
     const int32_t s0 = seg_lo[seg], s1 = seg_hi[seg];
     const int n = s1 - s0;
     if (n <= 0) { if (t == 0 && n_keep) n_keep[seg] = 0; return; }
-    if (n > kSegWave) return;  // k_merge_segments takes it
+    if (n > kSegWave) { if (t == 0 && long_list) long_list[atomicAdd(long_count, 1)] = seg; return; }  // k_merge_segments takes it (from this list)
     if (t == 0) npairs_s = 0;
     if (t < n) skey[t] = sort_key(conf[s0 + t]);
     sbits[t] = 0ull;
@@ -1485,19 +1523,28 @@ int obb_nms_reduce(obb_ctx *ctx, const uint64_t *mask, int64_t n, uint8_t *keep,
 int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, int64_t n, double thr,
                          int32_t *order, uint8_t *keep, int32_t *n_keep, obb_stream_t s);
 
+// workgroups of the 512-row form the chip holds at once (its LDS: one per CU)
+static int merge_resident(obb_ctx *) {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
+    return ncu;
+}
+
 int obb_merge_segments(obb_ctx *ctx, const double *boxes, const int32_t *cls, const double *conf, const int32_t *seg_off,
                        int32_t nseg, int64_t n, double thr, int32_t *order, uint8_t *keep, obb_stream_t s) {
     OBB_REQUIRE(ctx, ctx && nseg >= 0 && n >= 0, "obb_merge_segments: bad arguments");
     if (nseg == 0 || n == 0) return OBB_OK;
     OBB_REQUIRE(ctx, boxes && cls && conf && seg_off && order && keep, "obb_merge_segments: NULL buffer");
     hipStream_t st = (hipStream_t)s;
-    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
+    // status word | count of segments longer than a wave takes | their list (built by k_merge_segments_wave, walked by k_merge_segments)
+    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256 + sizeof(int32_t) * (size_t)nseg);
     if (!status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_segments: workspace allocation failed");
-    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr, order, keep, (int32_t *)nullptr);
+    OBB_HIP(ctx, hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)nseg), dim3(64), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr, order, keep, (int32_t *)nullptr,
+                       status + 64, status + 1);
     if (n > kSegWave)  // (some segment may be longer than a wave takes)
-        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)nseg), dim3(1024), 0, st, boxes, cls, conf, seg_off, seg_off + 1, thr,
-                           order, keep, (int32_t *)nullptr, status, kSegWave, 0);
+        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)std::min<int>(nseg, merge_resident(ctx))), dim3(1024), 0, st, boxes, cls, conf,
+                           seg_off, seg_off + 1, thr, order, keep, (int32_t *)nullptr, status, kSegWave, 0, status + 64, status + 1);
     OBB_LAUNCH_CHECK(ctx);
     if (n <= kSegMax) return OBB_OK;  // no segment can be longer than the LDS-resident kernel takes
     // Segments above kSegMax rows were flagged and left untouched by the kernel (a tile with more than 512 detections: max_det > 512, or
@@ -1539,9 +1586,11 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         if (!segoff || !status) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
         hipLaunchKernelGGL(k_set_segment, dim3(1), dim3(64), 0, st, segoff, (int32_t)n, status);  // (a kernel, not a host copy: capturable, no host memory referenced at replay)
         if (n <= kSegMid)
-            hipLaunchKernelGGL((k_merge_segments<kSegMid, 256, kSegMidPairCap>), dim3(1), dim3(256), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0);
+            hipLaunchKernelGGL((k_merge_segments<kSegMid, 256, kSegMidPairCap>), dim3(1), dim3(256), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0,
+                               (const int32_t *)nullptr, (const int32_t *)nullptr);
         else
-            hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0);
+            hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3(1), dim3(1024), 0, st, boxes, cls, conf, segoff, segoff + 1, thr, order, keep, n_keep, status, 0, 0,
+                               (const int32_t *)nullptr, (const int32_t *)nullptr);
         OBB_LAUNCH_CHECK(ctx);
         return OBB_OK;
     }
@@ -1687,7 +1736,7 @@ int obb_tile_survivors(obb_ctx *ctx, const float *det, const int32_t *count, int
     // scratch: staging rows + merge outputs (grow-only workspace slots of the context)
     const size_t a_bytes = (size_t)cap * (64 + 8 + 32 + 4 + 4) + 256, b_bytes = (size_t)cap * (4 + 1) + (size_t)B * 12 + 1024;
     char *wa = (char *)ctx->workspace(WS_SURV_A, a_bytes), *wb = (char *)ctx->workspace(WS_SURV_B, b_bytes);
-    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256);
+    int32_t *status = (int32_t *)ctx->workspace(WS_GEOM_E, 256 + sizeof(int32_t) * (size_t)B);  // status | long-segment count | their list
     if (!wa || !wb || !status) return set_error(ctx, OBB_ERR_HIP, "obb_tile_survivors: workspace allocation failed");
     SurvStage S;
     S.gb = (double *)wa; S.conf = (double *)(wa + (size_t)cap * 64); S.pts = (float *)(wa + (size_t)cap * 72); S.cls = (int32_t *)(wa + (size_t)cap * 104);
@@ -1696,11 +1745,12 @@ int obb_tile_survivors(obb_ctx *ctx, const float *det, const int32_t *count, int
     S.lo = (int32_t *)(wb + (size_t)cap * 4); S.hi = S.lo + B;
     int32_t *nkeep = S.hi + B;
     uint8_t *keep = (uint8_t *)(nkeep + B + 4);
-    OBB_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    OBB_HIP(ctx, hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_tile_stage, dim3((unsigned)B), dim3(256), 0, st, det, count, (int)max_det, lb, tile_ids, rects, (int)margin, (int)strike_cls, S);
-    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)B), dim3(64), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep);
-    if (max_det > kSegWave)  // (tiles with more than 64 survivors: the workgroup-per-segment form; shorter segments return at once)
-        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)B), dim3(1024), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep, status, kSegWave, 0);
+    hipLaunchKernelGGL(k_merge_segments_wave, dim3((unsigned)B), dim3(64), 0, st, S.gb, S.cls, S.conf, S.lo, S.hi, iou_thr, order, keep, nkeep, status + 64, status + 1);
+    if (max_det > kSegWave)  // (tiles with more than 64 survivors: resident workgroups walk the list the wave kernel left)
+        hipLaunchKernelGGL((k_merge_segments<kSegMax, 1024, kSegPairCap>), dim3((unsigned)std::min<int>(B, merge_resident(ctx))), dim3(1024), 0, st, S.gb, S.cls, S.conf, S.lo,
+                           S.hi, iou_thr, order, keep, nkeep, status, kSegWave, 0, status + 64, status + 1);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, nkeep, (int)B, tile_off, n_records);
     hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)B), dim3(64), 0, st, S, order, keep, tile_off, tile_ids, records);
     OBB_LAUNCH_CHECK(ctx);

@@ -754,6 +754,7 @@ __device__ __forceinline__ void merge_segment(const int seg, const double *__res
         sord[rank] = t;
     }
     __syncthreads();
+    double *sarea = skey;  // (the keys are spent: the rows' areas from here on)
     int W = (n + 63) / 64;
     for (int t = threadIdx.x; t < n; t += NT) {
         int src = s0 + sord[t];
@@ -761,9 +762,11 @@ __device__ __forceinline__ void merge_segment(const int seg, const double *__res
         P2 p[4];
         for (int k = 0; k < 4; ++k) { p[k].x = boxes[(int64_t)src * 8 + 2 * k]; p[k].y = boxes[(int64_t)src * 8 + 2 * k + 1]; }
         BoxMeta m;
-        if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; }
+        double area = 0.0;
+        if (quad_valid(p)) { Aabb a = quad_aabb(p); m.x0 = a.x0; m.y0 = a.y0; m.x1 = a.x1; m.y1 = a.y1; area = fabs(shoelace2<4>(p, 4)) * 0.5; }
         else { m.x0 = 1.0; m.x1 = -1.0; m.y0 = 1.0; m.y1 = -1.0; }
         smeta[t] = m;
+        sarea[t] = area;
         scl[t] = cls[src];
         for (int w = 0; w < kSegWords; ++w) sbits[t * kSegWords + w] = 0ull;
     }
@@ -781,10 +784,21 @@ __device__ __forceinline__ void merge_segment(const int seg, const double *__res
             const int i0 = part * chunk, i1 = min(min(i0 + chunk, n), j);
             const int cj = scl[j];
             const BoxMeta mj = smeta[j];
+            const double aj = sarea[j];
             for (int i = i0; i < i1; ++i) {
                 if (scl[i] != cj) continue;
                 if (all_hit) { atomicOr(&sbits[i * kSegWords + (j >> 6)], 1ull << (j & 63)); continue; }
-                if (!meta_overlap(smeta[i], mj)) continue;
+                const BoxMeta mi = smeta[i];
+                if (!meta_overlap(mi, mj)) continue;
+                // the intersection lies inside both envelopes and inside either quad: IoU <= ub / (a_i + a_j - ub) with ub = min(area of
+                // the envelopes' overlap, a_i, a_j).  A pair whose bound is below the threshold by more than any rounding of the exact
+                // evaluation (relative 1e-9 against ~1e-15) cannot be a hit: it never reaches the clip -- the decisions are unchanged.
+                {
+                    const double ai = sarea[i];
+                    const double ub = fmin(fmin(ai, aj), (fmin(mi.x1, mj.x1) - fmax(mi.x0, mj.x0)) * (fmin(mi.y1, mj.y1) - fmax(mi.y0, mj.y0)));
+                    const double den = ai + aj - ub;
+                    if (den > 0.0 && ub * (1.0 + 1e-9) < thr * den) continue;
+                }
                 const unsigned int slot = atomicAdd(&npairs_s, 1u);
                 if (slot < (unsigned)kSegPairCap) spairs[slot] = ((unsigned)i << 16) | (unsigned)j;
                 else {  // list full (pathologically crowded tile): clip right here (general routine: no LDS buffer for every thread)

@@ -63,6 +63,9 @@ const char *obb_last_error(const obb_ctx *ctx);
  *     "nitile"    (16-bit modes) several whole images per tile on the 4 x 4 / 2 x 2 maps of small tiles (3x3 convs with 64-cout groups)
  *     "nc2"       (fp32) two cout fragments per wave (32 couts x <= 64 pixels) in the conv kernel where the plan allows: a third fewer LDS reads
  *     "xtile"     (fp32) conv workgroups stay resident and walk several tiles, the next tile's first stage fetched under this tile's last k loop
+ *     "blk32"     (fp32) the tensors read by 3x3 convs in 8- / 16-channel stages stored as 8-channel blocks per image
+ *     "c3k2f"     (fp32) Bottleneck + closing 1x1 of the 104 x 104 C3k2 block in one launch (k_c3k2_f32)
+ *     "pw32"      (fp32) 1x1 layers with >= 64 input channels on k_pw_f32: weights resident in LDS, activations straight from global memory
  *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 0..4
  *   concurrent sub-batch chains (default 0 = 2), "microbatch" 416 x 416 tiles per round (default and maximum 1024; smaller tiles
  *   get proportionally more per round, at most 8192: 128 px -> 8192). */

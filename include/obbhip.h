@@ -68,7 +68,7 @@ const char *obb_last_error(const obb_ctx *ctx);
  *     "pw32"      (fp32) 1x1 layers with >= 64 input channels on k_pw_f32: weights resident in LDS, activations straight from global memory
  *   issue of a forward (take effect at the next obb_forward): "graph" 1 = capture / replay hipGraphs (default), "fwd_split" 0..4
  *   concurrent sub-batch chains (default 0 = 2), "microbatch" 416 x 416 tiles per round (default and maximum 1024; smaller tiles
- *   get proportionally more per round, at most 8192: 128 px -> 8192). */
+ *   get proportionally more per round, at most 16 384: 128 px -> 11 264). */
 int obb_set_option(obb_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ S2: compute_polygon_iou  (Detect_OBB.py:144-154) */

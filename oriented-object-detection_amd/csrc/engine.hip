@@ -1381,10 +1381,10 @@ int obb_forward_gate(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, i
     int rc = get_plan(ctx, h, w, &P);
     if (rc) return rc;
     // The batch is walked in sub-batches: bounds the activation slab (and keeps every 1-D launch inside 32-bit buffer offsets)
-    // "microbatch" counts 416 x 416 tiles: smaller tiles get proportionally more per round (128 px: 8192) -- the same activation bytes and
+    // "microbatch" counts 416 x 416 tiles: smaller tiles get proportionally more per round (128 px: 11 264 -- the 10 764 tiles of the dual-scale map are ONE round of two 5382-tile chains --, at most 16 384) -- the same activation bytes and
     // launch sizes, instead of 1024-tile rounds whose 4 x 4 / 8 x 8 levels are 74-WG launches on a 256-CU chip.  (measured at 416 px,
     // B = 1024: rounds of 512 / 1024 -> 91.8 / 94.7 k tiles/s; 128 / 256: 67 / 79 k with the round-1 kernels)
-    const int max_mb = (int)std::min<int64_t>(8192, (int64_t)ctx->opt.microbatch * std::max<int64_t>(1, (416 * 416) / ((int64_t)h * w)));
+    const int max_mb = (int)std::min<int64_t>(16384, (int64_t)ctx->opt.microbatch * std::max<int64_t>(1, (416 * 416 + (int64_t)h * w - 1) / ((int64_t)h * w)));
     rc = ensure_capacity(ctx, *P, std::min<int>(B, max_mb));
     if (rc) return rc;
     bool use_graph = ctx->opt.graph;
@@ -1393,8 +1393,8 @@ int obb_forward_gate(obb_ctx *ctx, const uint8_t *tiles, int32_t B, int32_t h, i
         if (hipStreamIsCapturing((hipStream_t)s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) use_graph = false;
     }
     hipStream_t st = (hipStream_t)s;
-    // (equal rounds: 10 764 tiles of 128 px are 2 x 5382, not 8192 + 2572 -- the short round ran its small-map layers at a third of the
-    // workgroups the chip holds)
+    // (equal rounds: 21 000 tiles of 128 px are 3 x 7000, not 10 240 + 10 240 + 520 -- a short round runs its small-map layers at a fraction of
+    // the workgroups the chip holds)
     const int nrounds = (B + max_mb - 1) / max_mb, per_round = (B + nrounds - 1) / nrounds;
     for (int b0 = 0; b0 < B; b0 += per_round) {
         int nb = std::min<int>(per_round, B - b0);

@@ -195,6 +195,33 @@ def test_merge_segments_vs_oracle(ops):
         assert np.array_equal(keep[off[k]:off[k + 1]], ek), k
 
 
+def test_merge_segments_many_long_segments_walk_the_device_list(ops):
+    """More long segments (65 .. 512 rows) than the chip holds workgroups of the 512-row kernel: the resident workgroups walk the device-side
+    list that the wave kernel builds, several segments each (LDS reused between them); mixed with short and empty segments.  One segment is
+    a single-class pile of near-duplicates (every pair a candidate: the pair list overflows into the in-place clips, and the IoU upper bound
+    sits at the threshold for many pairs).  Against the C oracle, bit for bit."""
+    rng = np.random.default_rng(11)
+    sizes = [int(v) for v in rng.choice([0, 3, 40, 64, 65, 90, 130, 200, 300, 512], size=640, p=[.05, .05, .1, .05, .15, .2, .2, .1, .05, .05])]
+    sizes[7] = 180
+    bs, cs, ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        b, c, s, _ = synth.make_dets(2000 + k, n, extent=120.0 + 3.0 * n) if n else (np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros(0), None)
+        if k == 7:  # the pile: one class, boxes jittered by a pixel or two
+            b = np.repeat(b[:1], n, 0) + rng.normal(0, 1.5, (n, 8))
+            c = np.zeros(n, np.int32)
+        bs.append(b); cs.append(c); ss.append(s); off.append(off[-1] + n)
+    assert sum(n > 64 for n in sizes) > 300
+    B, Cc, S = np.concatenate(bs), np.concatenate(cs), np.concatenate(ss)
+    order, keep = ops.merge_segments(dev(B, torch.float64), dev(Cc, torch.int32), dev(S, torch.float64), dev(np.array(off), torch.int32), 0.4)
+    order, keep = order.cpu().numpy(), keep.cpu().numpy()
+    for k, n in enumerate(sizes):
+        if n == 0:
+            continue
+        eo, ek = og.merge_arrays(bs[k], cs[k], ss[k], 0.4)
+        assert np.array_equal(order[off[k]:off[k + 1]], eo + off[k]), k
+        assert np.array_equal(keep[off[k]:off[k + 1]], ek), (k, n)
+
+
 def test_merge_segments_longer_than_the_lds_kernel(ops):
     """a tile with more than 512 detections (max_det > 512, or a foreign model without a cap): such segments used to be dropped silently;
     they now go through the dense path, the short ones around them through the LDS kernel, all in one call"""

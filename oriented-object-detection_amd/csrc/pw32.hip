@@ -7,11 +7,16 @@
 //   * a workgroup owns ONE 64-cout block: its weights (K x 64 floats, <= 80 KB) go to LDS once, in A-fragment order, and stay there while the
 //     workgroup walks pixel tiles -- the only barrier of the kernel is behind that load;
 //   * a lane's B operand of a 16-channel piece is one 16-byte load of ITS pixel (lane = pixel pl, chunk g): exactly the operand layout, so
-//     nothing is staged, committed or synchronised; a wave owns MFM fragments of 16 pixels x 4 cout fragments, i.e. 4 LDS reads (weights)
-//     + MFM global loads per 16 MFM MFMAs, and runs free of the other waves;
+//     nothing is staged, committed or synchronised; a wave's tile is 3 fragments of 16 pixels x 4 cout fragments, i.e. 4 LDS reads (weights)
+//     + 3 global loads per 48 MFMAs, and it runs free of the other waves: the fragments are dealt out per wave in contiguous ranges
+//     (a 2- / 1-fragment tail tile at the end) and the next tile's first two pieces are loaded under this tile's epilogue;
 //   * the loads of piece p + 2 are issued behind the MFMAs of piece p (two register sets, the piece loop unrolled by two so that no register
 //     is copied: a rotation `cur = next` would wait for the youngest load, see profiles/r03_summary.md);
 //   * k order = (piece, element s) exactly as k_conv_f32's 64-channel stages: BIT-IDENTICAL results (test).
+// Measured (profiles/r04_summary.md): the 25 layers 3.65 -> 3.3 ms per 512 tiles, forward 32.13 -> 31.45 ms per 1024 tiles.  Timing-only
+// ablations of the 26 x 26 layers (177 us): without the in-loop loads 163, without the stores 161 -- neither the loads nor the stores are
+// the bound; the 52 x 52 layers move 1.24 GB for 34 GFLOP (HBM and MFMA time about equal).  The two virtual upsample-concat layers were tried
+// on this kernel and stay on k_conv_f32 (no gain: the coarse-pixel arithmetic costs the registers of the cross-tile prefetch).
 // Row order of the weights (pack_pw32_weights): a lane ends with 16 consecutive output channels of its pixel (64 contiguous bytes / two
 // 8-channel blocks).
 #include "pw32.h"

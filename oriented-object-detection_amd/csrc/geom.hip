@@ -1124,51 +1124,64 @@ __global__ __launch_bounds__(256) void k_cons_edges(const double *__restrict__ b
 __global__ __launch_bounds__(1024) void k_cons_resolve(const double *__restrict__ conf, int64_t total, double cons_high, uint8_t *__restrict__ state,
                                                       const int32_t *__restrict__ adj_idx, const double *__restrict__ adj_iou, const int32_t *__restrict__ deg,
                                                       int32_t *__restrict__ decision, int32_t *__restrict__ emit, int32_t *__restrict__ flags,
-                                                      int32_t *__restrict__ out_idx, int32_t *__restrict__ n_out) {
+                                                      int32_t *__restrict__ work, int32_t *__restrict__ out_idx, int32_t *__restrict__ n_out) {
     if (flags[0]) return;  // adjacency overflow: k_consensus (launched behind this kernel) does the walk
-    __shared__ int s_any, s_base, s_wsum[16];
+    __shared__ int s_cnt, s_base, s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // rows that still wait for a decision, two lists in turn (after the first round a few percent of the rows are left: every later round
+    // walks those instead of all `total` rows -- 63 k rows: 0.59 -> see profiles/r04_summary.md)
+    int32_t *lists[2] = {work, work + total};
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     for (int64_t i = tid; i < total; i += 1024) {
         int e = -1;
-        if (state[i] == 1 && deg[i] == 0) { e = conf[i] >= cons_high ? (int32_t)i : -1; state[i] = 3; }  // no candidate partner at all: :406-410
+        if (state[i] == 1) {
+            if (deg[i] == 0) { e = conf[i] >= cons_high ? (int32_t)i : -1; state[i] = 3; }  // no candidate partner at all: :406-410
+            else lists[0][atomicAdd(&s_cnt, 1)] = (int32_t)i;
+        }
         emit[i] = e;
     }
     __syncthreads();
-    for (int64_t round = 0; round <= total; ++round) {
-        if (tid == 0) s_any = 0;
+    int n_cur = s_cnt;
+    for (int64_t round = 0; round <= total && n_cur > 0; ++round) {
+        const int32_t *cur = lists[round & 1];
+        int32_t *nxt = lists[(round + 1) & 1];
         __syncthreads();
-        for (int64_t i = tid; i < total; i += 1024) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int q = tid; q < n_cur; q += 1024) {  // decisions against the states of the round's start (nothing is written here but the lists)
+            const int i = cur[q];
             int dec = -2;  // not this round
-            if (state[i] == 1) {
-                const int di = deg[i];
-                bool ready = true;
-                for (int a = 0; a < di && ready; ++a) {
-                    const int j = adj_idx[i * kConsK + a];
-                    if (state[j] != 1) continue;  // visited: no longer a candidate, and it blocks nothing
-                    if (j < i) { ready = false; break; }  // j is walked before i and may or may not take i
-                    const int dj = deg[j];
-                    for (int b = 0; b < dj; ++b) {
-                        const int k = adj_idx[j * kConsK + b];
-                        if (k < i && state[k] == 1) { ready = false; break; }  // an earlier rival for j has not decided yet
-                    }
+            if (state[i] != 1) { decision[i] = dec; continue; }  // taken as a partner while it waited: gone from the lists
+            const int di = deg[i];
+            bool ready = true;
+            for (int a = 0; a < di && ready; ++a) {
+                const int j = adj_idx[(int64_t)i * kConsK + a];
+                if (state[j] != 1) continue;  // visited: no longer a candidate, and it blocks nothing
+                if (j < i) { ready = false; break; }  // j is walked before i and may or may not take i
+                const int dj = deg[j];
+                for (int b = 0; b < dj; ++b) {
+                    const int k = adj_idx[(int64_t)j * kConsK + b];
+                    if (k < i && state[k] == 1) { ready = false; break; }  // an earlier rival for j has not decided yet
                 }
-                if (ready) {
-                    double bc = -1.0, bi = 0.0;
-                    int bj = -1;
-                    for (int a = 0; a < di; ++a) {
-                        const int j = adj_idx[i * kConsK + a];
-                        if (state[j] != 1) continue;
-                        const double cp = conf[j], iou = adj_iou[i * kConsK + a];
-                        // :397-399 with the pool scanned in ascending position: higher confidence, then higher IoU, then the earlier one
-                        if (bj < 0 || cp > bc || (cp == bc && (iou > bi || (iou == bi && j < bj)))) { bc = cp; bi = iou; bj = j; }
-                    }
-                    dec = bj;
-                } else s_any = 1;
             }
+            if (ready) {
+                double bc = -1.0, bi = 0.0;
+                int bj = -1;
+                for (int a = 0; a < di; ++a) {
+                    const int j = adj_idx[(int64_t)i * kConsK + a];
+                    if (state[j] != 1) continue;
+                    const double cp = conf[j], iou = adj_iou[(int64_t)i * kConsK + a];
+                    // :397-399 with the pool scanned in ascending position: higher confidence, then higher IoU, then the earlier one
+                    if (bj < 0 || cp > bc || (cp == bc && (iou > bi || (iou == bi && j < bj)))) { bc = cp; bi = iou; bj = j; }
+                }
+                dec = bj;
+            } else nxt[atomicAdd(&s_cnt, 1)] = i;
             decision[i] = dec;
         }
         __syncthreads();
-        for (int64_t i = tid; i < total; i += 1024) {
+        for (int q = tid; q < n_cur; q += 1024) {
+            const int i = cur[q];
             const int dec = decision[i];
             if (dec == -2) continue;
             if (dec < 0) emit[i] = conf[i] >= cons_high ? (int32_t)i : -1;  // :406-410
@@ -1176,9 +1189,9 @@ __global__ __launch_bounds__(1024) void k_cons_resolve(const double *__restrict_
             state[i] = 3;
         }
         __syncthreads();
-        if (!s_any) break;
-        __syncthreads();
+        n_cur = s_cnt;
     }
+    __syncthreads();
     // kept list = the emitting detections in walk order: ordered compaction of emit[]
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -1692,7 +1705,7 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
     uint8_t *scale_id = state + (((size_t)total + 127) & ~(size_t)127);
     int32_t *adj_idx = (int32_t *)ctx->workspace(WS_NMS_B, sizeof(int32_t) * (size_t)total * kConsK);
     double *adj_iou = (double *)ctx->workspace(WS_NMS_C, sizeof(double) * (size_t)total * kConsK);
-    int32_t *ibuf = (int32_t *)ctx->workspace(WS_GEOM_A, sizeof(int32_t) * ((size_t)total * 3 + 64));  // deg | decision | emit | flags
+    int32_t *ibuf = (int32_t *)ctx->workspace(WS_GEOM_A, sizeof(int32_t) * ((size_t)total * 5 + 64));  // deg | decision | emit | flags (64) | two work lists
     if (!adj_idx || !adj_iou || !ibuf) return set_error(ctx, OBB_ERR_HIP, "obb_consensus: workspace allocation failed");
     int32_t *deg = ibuf, *decision = ibuf + total, *emit = ibuf + 2 * total, *flags = ibuf + 3 * total;
     hipLaunchKernelGGL(k_cons_prep, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, boxes, conf, off, nscales, cons_low, state, scale_id, meta,
@@ -1706,7 +1719,7 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
         OBB_LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_cons_resolve, dim3(1), dim3(1024), 0, st, conf, total, cons_high, state, (const int32_t *)adj_idx, (const double *)adj_iou,
-                       (const int32_t *)deg, decision, emit, flags, out_idx, n_out);
+                       (const int32_t *)deg, decision, emit, flags, flags + 64, out_idx, n_out);
     OBB_LAUNCH_CHECK(ctx);
     // a detection with more than kConsK candidate partners (flags[0]): the walk itself, on untouched state (it re-derives state and meta)
     hipLaunchKernelGGL(k_consensus, dim3(1), dim3(256), 0, st, boxes, cls, conf, off, nscales, iou_partner, cons_low, cons_high, state,

@@ -1079,33 +1079,33 @@ __global__ __launch_bounds__(256) void k_cons_prep(const double *__restrict__ bo
 // One launch per scale b >= 1: its rows j in [j_base, j_end) against every row i of the EARLIER scales, [0, j_base) -- only pairs of different
 // scales are partners and a scale's rows are contiguous, so nothing else is enumerated (all pairs i < j: 2.07 ms for 51 k + 12 k rows; with
 // the same-scale blocks returning at once 1.03 ms; this grid: see profiles/r04_summary.md).  grid (ceil((j_end - j_base) / 256),
-// ceil(j_base / 64)): thread = one j, block row = 64 i's held in LDS.
+// ceil(j_base / 256)): thread = one j, block row = 256 i's held in LDS (class in one word, -1 = takes no part: one compare per pair).
+template <int IB /* i rows per block: 256, or 64 when that fills the chip better */>
 __global__ __launch_bounds__(256) void k_cons_edges(const double *__restrict__ boxes, const int32_t *__restrict__ cls, const uint8_t *__restrict__ state,
                                                    const uint8_t *__restrict__ scale_id, const BoxMeta *__restrict__ meta, int64_t j_base, int64_t j_end, double iou_thr,
                                                    int32_t *__restrict__ adj_idx, double *__restrict__ adj_iou, int32_t *__restrict__ deg,
                                                    int32_t *__restrict__ flags) {
-    __shared__ BoxMeta sm[64];
-    __shared__ int32_t sc[64];
-    __shared__ int16_t ss[64];  // scale id, or -1 for a detection that takes no part (below CONS_LOW)
+    __shared__ BoxMeta sm[IB];
+    __shared__ int32_t sc[IB];  // class, or -1 for a detection that takes no part (below CONS_LOW): ONE compare per candidate i in the loop
     __shared__ __attribute__((aligned(16))) P2 sclip[kClipCap * 256];  // lane-private clip buffers (clip_area_convex)
-    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = j_base + (int64_t)blockIdx.x * 256;
-    const int64_t total = j_base;  // (bound of the i rows)
-    if (threadIdx.x < 64) {
+    const int64_t i0 = (int64_t)blockIdx.y * IB, j0 = j_base + (int64_t)blockIdx.x * 256;
+    const int64_t total = j_base;  // (bound of the i rows: every one of them belongs to an earlier scale than j's)
+    if ((int)threadIdx.x < IB) {
         const int64_t i = i0 + threadIdx.x;
         const bool ok = i < total && state[i] == 1;
-        ss[threadIdx.x] = ok ? (int16_t)scale_id[i] : (int16_t)-1;
-        sc[threadIdx.x] = ok ? cls[i] : 0;
+        sc[threadIdx.x] = ok ? cls[i] : -1;
         if (i < total) sm[threadIdx.x] = meta[i];
     }
     __syncthreads();
     const int64_t j = j0 + threadIdx.x;
     if (j >= j_end || state[j] != 1) return;
     const BoxMeta mj = meta[j];
-    const int cj = cls[j], sj = scale_id[j];
-    for (int r = 0; r < 64; ++r) {
+    const int cj = cls[j];
+    const int nr = (int)(total - i0 < IB ? total - i0 : IB);
+    for (int r = 0; r < nr; ++r) {
+        if (sc[r] != cj) continue;
+        if (!meta_overlap(sm[r], mj)) continue;
         const int64_t i = i0 + r;
-        if (i >= total) break;
-        if (ss[r] < 0 || ss[r] == sj || sc[r] != cj || !meta_overlap(sm[r], mj)) continue;
         P2 p[4], q[4];
         for (int k = 0; k < 4; ++k) {
             p[k].x = boxes[i * 8 + 2 * k]; p[k].y = boxes[i * 8 + 2 * k + 1];
@@ -1714,8 +1714,12 @@ int obb_consensus(obb_ctx *ctx, const double *boxes, const int32_t *cls, const d
     for (int b = 1; b < nscales; ++b) {
         const int64_t jb = off_host[b], je = off_host[b + 1];
         if (je <= jb || jb <= 0) continue;
-        hipLaunchKernelGGL(k_cons_edges, dim3((unsigned)cdiv(je - jb, 256), (unsigned)cdiv(jb, 64)), dim3(256), 0, st, boxes, cls, (const uint8_t *)state,
-                           (const uint8_t *)scale_id, (const BoxMeta *)meta, jb, je, iou_partner, adj_idx, adj_iou, deg, flags);
+        if (cdiv(je - jb, 256) * cdiv(jb, 256) >= 2048)
+            hipLaunchKernelGGL(k_cons_edges<256>, dim3((unsigned)cdiv(je - jb, 256), (unsigned)cdiv(jb, 256)), dim3(256), 0, st, boxes, cls, (const uint8_t *)state,
+                               (const uint8_t *)scale_id, (const BoxMeta *)meta, jb, je, iou_partner, adj_idx, adj_iou, deg, flags);
+        else
+            hipLaunchKernelGGL(k_cons_edges<64>, dim3((unsigned)cdiv(je - jb, 256), (unsigned)cdiv(jb, 64)), dim3(256), 0, st, boxes, cls, (const uint8_t *)state,
+                               (const uint8_t *)scale_id, (const BoxMeta *)meta, jb, je, iou_partner, adj_idx, adj_iou, deg, flags);
         OBB_LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_cons_resolve, dim3(1), dim3(1024), 0, st, conf, total, cons_high, state, (const int32_t *)adj_idx, (const double *)adj_iou,

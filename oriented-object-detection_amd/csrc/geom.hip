@@ -167,10 +167,13 @@ static constexpr int64_t kBucketSortMin = 8192;
 
 struct SortInfo { unsigned long long lo; int shift; };
 
-__global__ __launch_bounds__(1024) void k_sort_range(const double *__restrict__ key, int64_t n, SortInfo *__restrict__ info) {
+// smallest / largest key image in two steps (kSortParts workgroups reduce a slice each, one thread combines: exact, order-independent)
+static constexpr int kSortParts = 64;
+__global__ __launch_bounds__(1024) void k_sort_range_part(const double *__restrict__ key, int64_t n, unsigned long long *__restrict__ part /* [kSortParts][2] */) {
     __shared__ unsigned long long smin[1024], smax[1024];
     unsigned long long lo = ~0ull, hi = 0ull;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) { const unsigned long long u = sort_image(key[i]); lo = u < lo ? u : lo; hi = u > hi ? u : hi; }
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < n ? b0 + per : n;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 1024) { const unsigned long long u = sort_image(key[i]); lo = u < lo ? u : lo; hi = u > hi ? u : hi; }
     smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
     __syncthreads();
     for (int d = 512; d >= 1; d >>= 1) {
@@ -180,12 +183,17 @@ __global__ __launch_bounds__(1024) void k_sort_range(const double *__restrict__ 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const unsigned long long range = smax[0] - smin[0];
-        int sh = 0;
-        while (sh < 63 && (range >> sh) >= (unsigned long long)kSortBuckets) ++sh;
-        info->lo = smin[0]; info->shift = sh;
-    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = smin[0]; part[2 * blockIdx.x + 1] = smax[0]; }
+}
+
+__global__ __launch_bounds__(64) void k_sort_range(const unsigned long long *__restrict__ part, int nparts, SortInfo *__restrict__ info) {
+    if (threadIdx.x != 0) return;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int k = 0; k < nparts; ++k) { lo = part[2 * k] < lo ? part[2 * k] : lo; hi = part[2 * k + 1] > hi ? part[2 * k + 1] : hi; }
+    const unsigned long long range = hi >= lo ? hi - lo : 0ull;
+    int sh = 0;
+    while (sh < 63 && (range >> sh) >= (unsigned long long)kSortBuckets) ++sh;
+    info->lo = lo; info->shift = sh;
 }
 
 __device__ __forceinline__ int sort_bucket(unsigned long long u, const SortInfo &I) {
@@ -318,10 +326,15 @@ static constexpr int64_t kGridMin = 8192;
 
 struct GridInfo { double ox, oy, inv_cell, small_max; int gw, gh, n_large, pad; };
 
-__global__ __launch_bounds__(1024) void k_grid_info(const BoxMeta *__restrict__ meta, int64_t n, GridInfo *__restrict__ info) {
+// extent statistics of the envelopes in two steps: kGridParts workgroups reduce a slice each (one workgroup reading all 2 MB of a 65 536-row
+// set took 42 us), a wave combines the partial results in a fixed order.  (The sum of the extents only sizes the cells: the candidate set, and
+// with it every result, does not depend on the cell size -- see the comment on the grid below.)
+static constexpr int kGridParts = 64;
+__global__ __launch_bounds__(1024) void k_grid_info_part(const BoxMeta *__restrict__ meta, int64_t n, double *__restrict__ part /* [kGridParts][7] */) {
     __shared__ double s0[1024], s1[1024], s2[1024], s3[1024], s4[1024], s5[1024], s6[1024];
     double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY, ext = 0.0, esum = 0.0, ecnt = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) {
         const BoxMeta m = meta[i];
         if (!(m.x0 <= m.x1)) continue;  // invalid quad: empty envelope, never a partner
         x0 = fmin(x0, m.x0); y0 = fmin(y0, m.y0); x1 = fmax(x1, m.x1); y1 = fmax(y1, m.y1);
@@ -341,19 +354,30 @@ __global__ __launch_bounds__(1024) void k_grid_info(const BoxMeta *__restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        GridInfo g;
-        g.n_large = 0; g.pad = 0; g.small_max = 0.0;
-        if (!(s0[0] <= s2[0])) { g.ox = g.oy = 0.0; g.inv_cell = 0.0; g.gw = g.gh = 1; }
-        else {
-            const double wx = s2[0] - s0[0], wy = s3[0] - s1[0];
-            double cell = fmax(fmin(s4[0], 4.0 * s5[0] / s6[0]), fmax(wx, wy) / (double)(kGridDim - 1));
-            g.small_max = cell;  // rows with a larger extent are "large"
-            cell = cell > 0.0 ? cell * (1.0 + 1e-9) : 1.0;  // (a hair larger than the largest small extent: centre distance < cell for overlapping small envelopes)
-            g.ox = s0[0]; g.oy = s1[0]; g.inv_cell = 1.0 / cell;
-            g.gw = min(kGridDim, (int)(wx / cell) + 1); g.gh = min(kGridDim, (int)(wy / cell) + 1);
-        }
-        *info = g;
+        double *o = part + (size_t)blockIdx.x * 7;
+        o[0] = s0[0]; o[1] = s1[0]; o[2] = s2[0]; o[3] = s3[0]; o[4] = s4[0]; o[5] = s5[0]; o[6] = s6[0];
     }
+}
+
+__global__ __launch_bounds__(64) void k_grid_info(const double *__restrict__ part, int nparts, GridInfo *__restrict__ info) {
+    if (threadIdx.x != 0) return;
+    double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY, ext = 0.0, esum = 0.0, ecnt = 0.0;
+    for (int k = 0; k < nparts; ++k) {  // (fixed order: deterministic)
+        const double *o = part + (size_t)k * 7;
+        x0 = fmin(x0, o[0]); y0 = fmin(y0, o[1]); x1 = fmax(x1, o[2]); y1 = fmax(y1, o[3]); ext = fmax(ext, o[4]); esum += o[5]; ecnt += o[6];
+    }
+    GridInfo g;
+    g.n_large = 0; g.pad = 0; g.small_max = 0.0;
+    if (!(x0 <= x1)) { g.ox = g.oy = 0.0; g.inv_cell = 0.0; g.gw = g.gh = 1; }
+    else {
+        const double wx = x1 - x0, wy = y1 - y0;
+        double cell = fmax(fmin(ext, 4.0 * esum / ecnt), fmax(wx, wy) / (double)(kGridDim - 1));
+        g.small_max = cell;  // rows with a larger extent are "large"
+        cell = cell > 0.0 ? cell * (1.0 + 1e-9) : 1.0;  // (a hair larger than the largest small extent: centre distance < cell for overlapping small envelopes)
+        g.ox = x0; g.oy = y0; g.inv_cell = 1.0 / cell;
+        g.gw = min(kGridDim, (int)(wx / cell) + 1); g.gh = min(kGridDim, (int)(wy / cell) + 1);
+    }
+    *info = g;
 }
 
 __device__ __forceinline__ int grid_cell(const BoxMeta &m, const GridInfo &g, int &cx, int &cy) {
@@ -1499,13 +1523,15 @@ int obb_sort_desc_stable(obb_ctx *ctx, const double *key, int64_t n, int32_t *or
     OBB_REQUIRE(ctx, key && order, "obb_sort_desc_stable: NULL buffer");
     if (n >= kBucketSortMin && n <= (int64_t)kSortHot * kSortHotMax) {  // bucketed O(n) form, same order element for element (the bound: every hot bucket fits the list)
         hipStream_t st = (hipStream_t)s;
-        int32_t *buf = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)n + 2 * (size_t)kSortBuckets + 64 + 2 * kSortHotMax + 8));
+        int32_t *buf = (int32_t *)ctx->workspace(WS_GEOM_C, sizeof(int32_t) * ((size_t)n + 2 * (size_t)kSortBuckets + 64 + 2 * kSortHotMax + 8 + 4 * kSortParts + 4));
         if (!buf) return set_error(ctx, OBB_ERR_HIP, "obb_sort_desc_stable: workspace allocation failed");
         int32_t *hist = buf, *start = buf + kSortBuckets + 8, *members = buf + 2 * kSortBuckets + 32;
         SortInfo *info = (SortInfo *)(buf + 2 * kSortBuckets + 16);
         int32_t *cursor = hist;  // the histogram is dead once scanned: reuse it as the scatter cursor
         OBB_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int32_t) * kSortBuckets, st));
-        hipLaunchKernelGGL(k_sort_range, dim3(1), dim3(1024), 0, st, key, n, info);
+        unsigned long long *rpart = (unsigned long long *)(buf + ((2 * (size_t)kSortBuckets + 32 + (size_t)n + 8 + 2 * kSortHotMax + 8 + 1) & ~(size_t)1));  // behind the hot list
+        hipLaunchKernelGGL(k_sort_range_part, dim3(kSortParts), dim3(1024), 0, st, key, n, rpart);
+        hipLaunchKernelGGL(k_sort_range, dim3(1), dim3(64), 0, st, (const unsigned long long *)rpart, kSortParts, info);
         hipLaunchKernelGGL(k_sort_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, hist);
         hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, kSortBuckets, start, cursor);
         hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, key, n, (const SortInfo *)info, cursor, members);
@@ -1674,12 +1700,14 @@ int obb_merge_detections(obb_ctx *ctx, const double *boxes, const int32_t *cls, 
         if (!edges) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
         if (n >= kGridMin) {  // candidate partners through a uniform grid instead of all pairs
             const int ncell = kGridDim * kGridDim;
-            int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * (2 * (size_t)n + 2 * (size_t)ncell + 64));
+            int32_t *gbuf = (int32_t *)ctx->workspace(WS_GEOM_D, sizeof(int32_t) * (2 * (size_t)n + 2 * (size_t)ncell + 64 + 2 * 7 * kGridParts + 2));
             if (!gbuf) return set_error(ctx, OBB_ERR_HIP, "obb_merge_detections: workspace allocation failed");
             int32_t *hist = gbuf, *start = gbuf + ncell + 8, *members = gbuf + 2 * ncell + 32, *large = members + n;
             GridInfo *ginfo = (GridInfo *)(gbuf + 2 * ncell + 16);
             OBB_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int32_t) * ncell, st));
-            hipLaunchKernelGGL(k_grid_info, dim3(1), dim3(1024), 0, st, (const BoxMeta *)meta, n, ginfo);
+            double *gpart = (double *)(gbuf + ((2 * (size_t)ncell + 32 + 2 * (size_t)n + 1) & ~(size_t)1));  // behind members | large, 8-byte aligned
+            hipLaunchKernelGGL(k_grid_info_part, dim3(kGridParts), dim3(1024), 0, st, (const BoxMeta *)meta, n, gpart);
+            hipLaunchKernelGGL(k_grid_info, dim3(1), dim3(64), 0, st, (const double *)gpart, kGridParts, ginfo);
             hipLaunchKernelGGL(k_grid_count, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, ginfo, hist, large);
             hipLaunchKernelGGL(k_cells_scan, dim3(1), dim3(1024), 0, st, (const int32_t *)hist, ncell, start, hist);
             hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const BoxMeta *)meta, n, (const GridInfo *)ginfo, hist, members);

@@ -451,33 +451,42 @@ __global__ __launch_bounds__(256) void k_grid_pairs(const double *__restrict__ s
         const bool j_large = grid_is_large(mj, g);
         int cx = 0, cy = 0;
         grid_cell(mj, g, cx, cy);
-        for (int ph = j_large ? 9 : 0; ph < 10; ++ph) {  // 9 cells (small j only), then the large rows
-            int cur, end;
-            const int32_t *src;
-            if (ph < 9) {
-                const int yy = cy - 1 + ph / 3, xx = cx - 1 + ph % 3;
-                if (yy < 0 || yy >= g.gh || xx < 0 || xx >= g.gw) continue;
-                const int c = yy * g.gw + xx;
-                cur = start[c]; end = start[c + 1]; src = members;
-            } else { cur = 0; end = g.n_large; src = large; }
-            for (int base = cur; base < end; base += 64) {
-                const int m = base + lane;
-                bool pass = false;
-                int i = -1;
-                if (m < end) {
-                    i = src[m];
-                    const bool take = ph == 9 ? (i != (int)j && (!j_large || i < (int)j)) : i < (int)j;
-                    pass = take && scls[i] == cj && meta_overlap(meta[i], mj);
+        // The members of the 3 x 3 cells around j (small j only) and the large rows as ONE index space: lane k < 9 fetches its cell's range, the
+        // ranges are laid end to end and walked 64 candidates at a time -- one round of (member, class + envelope) loads per 64 candidates
+        // instead of one per cell (a row's nine cells hold a handful of members each: nine dependent load chains per row were the kernel's time)
+        int cs = 0, len = 0;
+        if (!j_large && lane < 9) {
+            const int yy = cy - 1 + lane / 3, xx = cx - 1 + lane % 3;
+            if (yy >= 0 && yy < g.gh && xx >= 0 && xx < g.gw) { const int c = yy * g.gw + xx; cs = start[c]; len = start[c + 1] - cs; }
+        }
+        int CS[9], PR[9], ncell_m = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { CS[k] = __shfl(cs, k); PR[k] = ncell_m; ncell_m += __shfl(len, k); }
+        const int total = ncell_m + g.n_large;
+        for (int base = 0; base < total; base += 64) {
+            const int f = base + lane;
+            int i = -1;
+            bool take = false;
+            if (f < ncell_m) {
+                int m = CS[0] + f;
+#pragma unroll
+                for (int k = 1; k < 9; ++k) if (f >= PR[k]) m = CS[k] + (f - PR[k]);
+                i = members[m];
+                take = i < (int)j;
+            } else if (f < total) {
+                i = large[f - ncell_m];
+                take = i != (int)j && (!j_large || i < (int)j);
+            }
+            bool pass = false;
+            if (i >= 0) pass = take && scls[i] == cj && meta_overlap(meta[i], mj);
+            const unsigned long long bal = __ballot(pass);
+            if (bal) {
+                if (pass) {
+                    const unsigned long long lo = i < (int)j ? (unsigned long long)i : (unsigned long long)j, hi = i < (int)j ? (unsigned long long)j : (unsigned long long)i;
+                    q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (lo << 32) | hi;
                 }
-                const unsigned long long bal = __ballot(pass);
-                if (bal) {
-                    if (pass) {
-                        const unsigned long long lo = i < (int)j ? (unsigned long long)i : (unsigned long long)j, hi = i < (int)j ? (unsigned long long)j : (unsigned long long)i;
-                        q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (lo << 32) | hi;
-                    }
-                    qn += __popcll(bal);
-                    if (qn >= 64) clip64(64);
-                }
+                qn += __popcll(bal);
+                if (qn >= 64) clip64(64);
             }
         }
     }
